@@ -1,0 +1,164 @@
+"""Python face of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; nothing
+under semcode_amd/ does.  It wraps oracle/sc_oracle.c (built into oracle/_build/libsc_oracle.so by
+`build()`), and adds an independent numpy float64 brute force used to pin the C restatement.
+
+Parity status: "parity unpinned" at the third-party boundary (see the header of sc_oracle.c).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+SRC = HERE / "sc_oracle.c"
+LIB = HERE / "_build" / "libsc_oracle.so"
+
+METRICS = {"IP": 0, "L2": 1, "COSINE": 2}
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """gcc -O2 -mfma -fopenmp; x86-64-v3 only (no -march=native: the .so travels to the GPU box)."""
+    if not force and LIB.exists() and LIB.stat().st_mtime >= SRC.stat().st_mtime:
+        return LIB
+    gcc = shutil.which("gcc")
+    if not gcc:
+        raise RuntimeError("gcc not found: cannot build the oracle")
+    LIB.parent.mkdir(exist_ok=True)
+    cmd = [gcc, "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
+           str(SRC), "-o", str(LIB), "-lm"]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        h = C.CDLL(str(LIB))
+        h.sc_oracle_synth.restype = C.c_float
+        h.sc_oracle_synth.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        h.sc_oracle_synth_fill.restype = None
+        h.sc_oracle_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int64]
+        h.sc_oracle_sqnorm.restype = C.c_float
+        h.sc_oracle_sqnorm.argtypes = [C.c_void_p, C.c_int32]
+        h.sc_oracle_dot.restype = C.c_float
+        h.sc_oracle_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        h.sc_oracle_score.restype = C.c_float
+        h.sc_oracle_score.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float]
+        h.sc_oracle_search.restype = None
+        h.sc_oracle_search.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                       C.c_void_p, C.c_void_p]
+        h.sc_oracle_search_rows.restype = None
+        h.sc_oracle_search_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                            C.c_void_p, C.c_void_p]
+        h.sc_oracle_threads.restype = C.c_int32
+        _lib = h
+    return _lib
+
+
+def pad_ld(dim: int, align: int = 64) -> int:
+    return (dim + align - 1) // align * align
+
+
+def padded(a: np.ndarray, ld: int | None = None) -> np.ndarray:
+    """[n, dim] -> zero-padded contiguous [n, ld] float32 (the HBM row layout)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    ld = ld or pad_ld(a.shape[1])
+    if a.shape[1] == ld:
+        return a
+    out = np.zeros((a.shape[0], ld), dtype=np.float32)
+    out[:, : a.shape[1]] = a
+    return out
+
+
+def synth(rows: int, dim: int, seed: int, first_row: int = 0, ld: int | None = None) -> np.ndarray:
+    """The deterministic synthetic generator (bit-identical to the device kernel)."""
+    ld = ld or dim
+    out = np.empty((rows, ld), dtype=np.float32)
+    lib().sc_oracle_synth_fill(out.ctypes.data_as(C.c_void_p), rows, dim, ld, seed, first_row)
+    return out
+
+
+def synth_rows(rows_idx, dim: int, seed: int) -> np.ndarray:
+    """Regenerate arbitrary (global) rows of the synthetic corpus: random access, no storage."""
+    rows_idx = np.asarray(rows_idx, dtype=np.int64)
+    out = np.empty((len(rows_idx), dim), dtype=np.float32)
+    h = lib()
+    for i, r in enumerate(rows_idx):
+        h.sc_oracle_synth_fill(out[i].ctypes.data_as(C.c_void_p), 1, dim, dim, seed, int(r))
+    return out
+
+
+def sqnorm(x: np.ndarray) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().sc_oracle_sqnorm(x.ctypes.data_as(C.c_void_p), x.shape[0]))
+
+
+def dot(x: np.ndarray, q: np.ndarray) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    assert x.shape == q.shape and x.shape[0] % 16 == 0
+    return float(lib().sc_oracle_dot(x.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), x.shape[0]))
+
+
+def search(X: np.ndarray, Q: np.ndarray, k: int, metric: str = "L2", row_base: int = 0):
+    """Canonical-order exhaustive search.  X [n, dim], Q [nq, dim] -> (dist [nq,k] f32, rows [nq,k] i64)."""
+    Xp, Qp = padded(X), padded(Q)
+    assert Xp.shape[1] == Qp.shape[1]
+    nq = Qp.shape[0]
+    dist = np.empty((nq, k), dtype=np.float32)
+    rows = np.empty((nq, k), dtype=np.int64)
+    lib().sc_oracle_search(Xp.ctypes.data_as(C.c_void_p), Xp.shape[0], Xp.shape[1], METRICS[metric],
+                           Qp.ctypes.data_as(C.c_void_p), nq, k, row_base, dist.ctypes.data_as(C.c_void_p),
+                           rows.ctypes.data_as(C.c_void_p))
+    return dist, rows
+
+
+def search_rows(X: np.ndarray, q: np.ndarray, rows, k: int, metric: str = "L2"):
+    """Canonical-order search restricted to `rows` of X for one query."""
+    Xp, qp = padded(X), padded(q.reshape(1, -1))
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    dist = np.empty((k,), dtype=np.float32)
+    out = np.empty((k,), dtype=np.int64)
+    lib().sc_oracle_search_rows(Xp.ctypes.data_as(C.c_void_p), Xp.shape[1], METRICS[metric], qp.ctypes.data_as(C.c_void_p),
+                                rows.ctypes.data_as(C.c_void_p), len(rows), k, dist.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p))
+    return dist, out
+
+
+def threads() -> int:
+    return int(lib().sc_oracle_threads())
+
+
+# ---------------------------------------------------------------- independent float64 reference
+
+def search_f64(X: np.ndarray, Q: np.ndarray, k: int, metric: str = "L2"):
+    """numpy float64 brute force, tie rule (score, lower row).  Returns (score f64 [nq,k], rows i64 [nq,k])."""
+    X64 = np.asarray(X, dtype=np.float64)
+    Q64 = np.asarray(Q, dtype=np.float64)
+    dots = Q64 @ X64.T
+    if metric == "L2":
+        s = (X64 * X64).sum(1)[None, :] + (Q64 * Q64).sum(1)[:, None] - 2.0 * dots
+        order_key = s
+    elif metric == "COSINE":
+        s = dots / (np.sqrt((X64 * X64).sum(1))[None, :] * np.sqrt((Q64 * Q64).sum(1))[:, None])
+        order_key = -s
+    else:
+        s = dots
+        order_key = -s
+    n = X64.shape[0]
+    kk = min(k, n)
+    rows = np.full((Q64.shape[0], k), -1, dtype=np.int64)
+    score = np.full((Q64.shape[0], k), np.inf if metric == "L2" else -np.inf)
+    for i in range(Q64.shape[0]):
+        idx = np.lexsort((np.arange(n), order_key[i]))[:kk]
+        rows[i, :kk] = idx
+        score[i, :kk] = s[i, idx]
+    return score, rows

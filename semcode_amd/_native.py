@@ -1,0 +1,243 @@
+"""ctypes binding of libsemcode_hip.so (include/semcode_hip.h).
+
+This is the only place Python touches the C ABI.  There is no CPU fallback: if the shared
+library is missing, or no MI355X is visible when a runtime is created, the error is raised
+to the caller (the seams in embeddings/ and storage/ let it propagate as an ordinary
+exception, which IndexerService / SemanticSearchPipeline already catch --
+reference src/semcode/services/indexer.py:57-63, src/semcode/rag/pipeline.py:95-110).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libsemcode_hip.so"
+
+METRICS = {"IP": 0, "L2": 1, "COSINE": 2}
+KINDS = {"FLAT": 0, "IVF_FLAT": 1}
+
+
+class ScError(RuntimeError):
+    """A libsemcode_hip call returned a negative sc_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libsemcode_hip error {status}: {message}")
+        self.status = status
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_int32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes): exactly the entry points include/semcode_hip.h declares
+SIGNATURES = {
+    "sc_version": (C.c_char_p, []),
+    "sc_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
+    "sc_runtime_create": (C.c_int32, [C.POINTER(_Cfg), C.POINTER(C.c_void_p)]),
+    "sc_runtime_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_runtime_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "sc_runtime_synchronize": (C.c_int32, [C.c_void_p]),
+    "sc_runtime_device_info": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "sc_runtime_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sc_runtime_profile_read": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "sc_runtime_profile_reset": (C.c_int32, [C.c_void_p]),
+    "sc_synth_fill_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int64]),
+    "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "sc_index_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_index_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_index_reserve": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "sc_index_add": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "sc_index_overwrite": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "sc_index_get_rows": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "sc_index_fill_synthetic": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
+    "sc_index_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_index_search_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_topk_merge_host": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -m semcode_amd.csrc.build` "
+                    "(needs hipcc); semcode_amd has no CPU fallback."
+                )
+            handle = C.CDLL(str(LIB_PATH))
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        buf = C.create_string_buffer(512)
+        lib().sc_last_error(buf, 512)
+        raise ScError(status, buf.value.decode("utf-8", "replace"))
+
+
+def _as_f32(a, shape_last: int | None = None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_last is not None and (arr.ndim != 2 or arr.shape[1] != shape_last):
+        raise ValueError(f"expected a [n, {shape_last}] float array, got shape {arr.shape}")
+    return arr
+
+
+class Runtime:
+    """One per process / GPU (sc_runtime)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        cfg = _Cfg(device=device, stream=C.c_void_p(stream) if stream else None, flags=0)
+        _check(lib().sc_runtime_create(C.byref(cfg), C.byref(self._h)))
+        self.device = device
+
+    def close(self) -> None:
+        if self._h:
+            lib().sc_runtime_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("runtime is closed")
+        return self._h
+
+    def set_stream(self, stream: int) -> None:
+        _check(lib().sc_runtime_set_stream(self.handle, C.c_void_p(stream)))
+
+    def synchronize(self) -> None:
+        _check(lib().sc_runtime_synchronize(self.handle))
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int32(), C.c_int64()
+        _check(lib().sc_runtime_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+    def set_profiling(self, enabled: bool) -> None:
+        _check(lib().sc_runtime_set_profiling(self.handle, 1 if enabled else 0))
+
+    def profile_read(self, which: int) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().sc_runtime_profile_read(self.handle, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self) -> None:
+        _check(lib().sc_runtime_profile_reset(self.handle))
+
+    def synth_fill_dev(self, dev_ptr: int, rows: int, dim: int, ld: int, seed: int, first_row: int = 0) -> None:
+        _check(lib().sc_synth_fill_dev(self.handle, C.c_void_p(dev_ptr), rows, dim, ld, seed, first_row))
+
+
+class Index:
+    """HBM-resident vector index (sc_index): FLAT or IVF_FLAT, metric IP / L2 / COSINE."""
+
+    def __init__(self, rt: Runtime, dim: int, metric: str = "IP", kind: str = "FLAT", nlist: int = 128, row_base: int = 0):
+        if metric not in METRICS:
+            raise ValueError(f"unknown metric {metric!r}")
+        if kind not in KINDS:
+            raise ValueError(f"unknown index kind {kind!r}")
+        self.rt = rt
+        self.dim = int(dim)
+        self.metric = metric
+        self.kind = kind
+        self.row_base = int(row_base)
+        self._h = C.c_void_p()
+        _check(lib().sc_index_create(rt.handle, self.dim, METRICS[metric], KINDS[kind], int(nlist), self.row_base, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().sc_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("index is closed")
+        return self._h
+
+    def info(self) -> dict:
+        rows, dim, ld = C.c_int64(), C.c_int32(), C.c_int32()
+        _check(lib().sc_index_info(self.handle, C.byref(rows), C.byref(dim), C.byref(ld)))
+        return {"rows": rows.value, "dim": dim.value, "ld": ld.value}
+
+    def __len__(self) -> int:
+        return self.info()["rows"]
+
+    def reserve(self, rows: int) -> None:
+        _check(lib().sc_index_reserve(self.handle, int(rows)))
+
+    def add(self, vecs) -> None:
+        v = _as_f32(vecs, self.dim)
+        _check(lib().sc_index_add(self.handle, v.ctypes.data_as(C.c_void_p), v.shape[0]))
+
+    def overwrite(self, vecs, rows) -> None:
+        v = _as_f32(vecs, self.dim)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        if r.shape != (v.shape[0],):
+            raise ValueError("rows must have one entry per vector")
+        _check(lib().sc_index_overwrite(self.handle, v.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), v.shape[0]))
+
+    def get_rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), dtype=np.float32)
+        _check(lib().sc_index_get_rows(self.handle, int(first), int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def fill_synthetic(self, n: int, seed: int, first_row: int = 0) -> None:
+        _check(lib().sc_index_fill_synthetic(self.handle, int(n), int(seed), int(first_row)))
+
+    def search(self, queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:
+        """queries [Q, dim] -> (dist [Q, k] f32, rows [Q, k] i64), best first."""
+        q = _as_f32(queries, self.dim)
+        Q = q.shape[0]
+        dist = np.empty((Q, k), dtype=np.float32)
+        rows = np.empty((Q, k), dtype=np.int64)
+        _check(lib().sc_index_search(self.handle, q.ctypes.data_as(C.c_void_p), Q, int(k), int(nprobe),
+                                     dist.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p)))
+        return dist, rows
+
+    def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
+        """Device-pointer variant (asynchronous on the runtime's stream)."""
+        _check(lib().sc_index_search_dev(self.handle, C.c_void_p(q_ptr), int(Q), int(k), int(nprobe), C.c_void_p(dist_ptr), C.c_void_p(rows_ptr)))
+
+
+def topk_merge_host(metric: str, dist: np.ndarray, rows: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Merge per-shard results dist/rows [lists, Q, k] -> global best-first [Q, k]."""
+    d = np.ascontiguousarray(dist, dtype=np.float32)
+    r = np.ascontiguousarray(rows, dtype=np.int64)
+    if d.ndim != 3 or d.shape != r.shape:
+        raise ValueError("dist and rows must both be [lists, Q, k]")
+    lists, Q, k = d.shape
+    od = np.empty((Q, k), dtype=np.float32)
+    orow = np.empty((Q, k), dtype=np.int64)
+    _check(lib().sc_topk_merge_host(METRICS[metric], lists, Q, k, d.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                                    od.ctypes.data_as(C.c_void_p), orow.ctypes.data_as(C.c_void_p)))
+    return od, orow

@@ -1,0 +1,468 @@
+// sc_api.cpp -- host side of the C ABI declared in include/semcode_hip.h (runtime + vector index).
+//
+// Mirrors (reference): MilvusVectorStore's use of pymilvus -- connect / create collection + index /
+// upsert / search -- src/semcode/storage/milvus_store.py:39-148.  Error behaviour: every failure is
+// a negative sc_status plus a thread-local message, so the Python seam can raise ordinary
+// exceptions that IndexerService / SemanticSearchPipeline already catch (indexer.py:57-63,
+// pipeline.py:95-110).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sc_internal.h"
+
+static thread_local std::string g_err;
+
+sc_status sc_fail(sc_status code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+extern "C" const char* sc_version(void) { return "semcode_hip 0.1 (gfx950)"; }
+
+extern "C" sc_status sc_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return SC_ERR_INVALID;
+    snprintf(buf, n, "%s", g_err.c_str());
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------ runtime
+
+extern "C" sc_status sc_runtime_create(const sc_runtime_cfg* cfg, sc_runtime** out) {
+    if (!out) return sc_fail(SC_ERR_INVALID, "sc_runtime_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return sc_fail(SC_ERR_HIP, "sc_runtime_create: no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    const int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= ndev) return sc_fail(SC_ERR_INVALID, "sc_runtime_create: device %d out of range [0,%d)", dev, ndev);
+    SC_HIP(hipSetDevice(dev));
+    sc_runtime* rt = new (std::nothrow) sc_runtime();
+    if (!rt) return sc_fail(SC_ERR_NOMEM, "sc_runtime_create: out of host memory");
+    rt->device = dev;
+    if (cfg && cfg->stream) {
+        rt->stream = (hipStream_t)cfg->stream;
+        rt->own_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete rt;
+            return sc_fail(SC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        rt->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        snprintf(rt->name, sizeof rt->name, "%s (%s)", prop.name, prop.gcnArchName);
+        rt->cus = prop.multiProcessorCount;
+        rt->hbm = (int64_t)prop.totalGlobalMem;
+    }
+    *out = rt;
+    return SC_OK;
+}
+
+static void prof_clear(sc_runtime* rt) {
+    for (int c = 0; c < SC_PROF_CLASSES; ++c) {
+        for (auto& p : rt->prof[c]) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        rt->prof[c].clear();
+    }
+}
+
+extern "C" sc_status sc_runtime_destroy(sc_runtime* rt) {
+    if (!rt) return SC_OK;
+    hipSetDevice(rt->device);
+    hipStreamSynchronize(rt->stream);
+    prof_clear(rt);
+    if (rt->own_stream) hipStreamDestroy(rt->stream);
+    delete rt;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_runtime_set_stream(sc_runtime* rt, void* stream) {
+    if (!rt) return sc_fail(SC_ERR_INVALID, "runtime is NULL");
+    std::lock_guard<std::mutex> g(rt->mu);
+    if (rt->own_stream) {
+        hipStreamSynchronize(rt->stream);
+        hipStreamDestroy(rt->stream);
+        rt->own_stream = false;
+    }
+    rt->stream = (hipStream_t)stream;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_runtime_synchronize(sc_runtime* rt) {
+    if (!rt) return sc_fail(SC_ERR_INVALID, "runtime is NULL");
+    SC_HIP(hipSetDevice(rt->device));
+    SC_HIP(hipStreamSynchronize(rt->stream));
+    return SC_OK;
+}
+
+extern "C" sc_status sc_runtime_device_info(sc_runtime* rt, char* name, size_t n, int32_t* cus, int64_t* hbm_bytes) {
+    if (!rt) return sc_fail(SC_ERR_INVALID, "runtime is NULL");
+    if (name && n) snprintf(name, n, "%s", rt->name);
+    if (cus) *cus = rt->cus;
+    if (hbm_bytes) *hbm_bytes = rt->hbm;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_runtime_set_profiling(sc_runtime* rt, int32_t enabled) {
+    if (!rt) return sc_fail(SC_ERR_INVALID, "runtime is NULL");
+    rt->profiling = enabled != 0;
+    return SC_OK;
+}
+
+void sc_prof_begin(sc_runtime* rt, int which, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
+    if (!rt->profiling || rt->prof[which].size() >= 8192) return;
+    if (hipEventCreate(a) != hipSuccess) { *a = nullptr; return; }
+    if (hipEventCreate(b) != hipSuccess) { hipEventDestroy(*a); *a = *b = nullptr; return; }
+    hipEventRecord(*a, rt->stream);
+}
+void sc_prof_end(sc_runtime* rt, int which, hipEvent_t a, hipEvent_t b) {
+    if (!a) return;
+    hipEventRecord(b, rt->stream);
+    std::lock_guard<std::mutex> g(rt->mu);
+    rt->prof[which].push_back({a, b});
+}
+
+extern "C" sc_status sc_runtime_profile_read(sc_runtime* rt, int32_t which, double* total_ms, int64_t* launches) {
+    if (!rt || which < 0 || which >= SC_PROF_CLASSES) return sc_fail(SC_ERR_INVALID, "bad profile class");
+    SC_HIP(hipSetDevice(rt->device));
+    SC_HIP(hipStreamSynchronize(rt->stream));
+    double t = 0;
+    std::lock_guard<std::mutex> g(rt->mu);
+    for (auto& p : rt->prof[which]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = (int64_t)rt->prof[which].size();
+    return SC_OK;
+}
+
+extern "C" sc_status sc_runtime_profile_reset(sc_runtime* rt) {
+    if (!rt) return sc_fail(SC_ERR_INVALID, "runtime is NULL");
+    SC_HIP(hipSetDevice(rt->device));
+    SC_HIP(hipStreamSynchronize(rt->stream));
+    std::lock_guard<std::mutex> g(rt->mu);
+    prof_clear(rt);
+    return SC_OK;
+}
+
+extern "C" sc_status sc_synth_fill_dev(sc_runtime* rt, float* out, int64_t rows, int32_t dim, int32_t ld, uint64_t seed,
+                                       int64_t first_row) {
+    if (!rt || !out) return sc_fail(SC_ERR_INVALID, "sc_synth_fill_dev: NULL argument");
+    if (rows < 0 || dim <= 0 || ld < dim || (ld & 3)) return sc_fail(SC_ERR_INVALID, "sc_synth_fill_dev: need rows>=0, 0<dim<=ld, ld%%4==0");
+    SC_HIP(hipSetDevice(rt->device));
+    sc_launch_synth_fill(out, rows, dim, ld, seed, first_row, nullptr, rt->stream);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------ index
+
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+extern "C" sc_status sc_index_create(sc_runtime* rt, int32_t dim, sc_metric metric, sc_index_kind kind, int32_t nlist,
+                                     int64_t row_base, sc_index** out) {
+    if (!rt || !out) return sc_fail(SC_ERR_INVALID, "sc_index_create: NULL argument");
+    *out = nullptr;
+    if (dim <= 0 || dim > 65536) return sc_fail(SC_ERR_INVALID, "sc_index_create: dim %d out of range", dim);
+    if (metric != SC_METRIC_IP && metric != SC_METRIC_L2 && metric != SC_METRIC_COSINE)
+        return sc_fail(SC_ERR_INVALID, "sc_index_create: unknown metric %d", (int)metric);
+    if (kind != SC_INDEX_FLAT && kind != SC_INDEX_IVF_FLAT) return sc_fail(SC_ERR_INVALID, "sc_index_create: unknown kind %d", (int)kind);
+    if (kind == SC_INDEX_IVF_FLAT && nlist < 1) return sc_fail(SC_ERR_INVALID, "sc_index_create: IVF_FLAT needs nlist >= 1");
+    sc_index* ix = new (std::nothrow) sc_index();
+    if (!ix) return sc_fail(SC_ERR_NOMEM, "out of host memory");
+    ix->rt = rt;
+    ix->dim = dim;
+    ix->ld = round_up(dim, SC_LD_ALIGN);
+    ix->metric = metric;
+    ix->kind = kind;
+    ix->nlist = nlist;
+    ix->row_base = row_base;
+    *out = ix;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_destroy(sc_index* ix) {
+    if (!ix) return SC_OK;
+    hipSetDevice(ix->rt->device);
+    hipStreamSynchronize(ix->rt->stream);
+    hipFree(ix->X);
+    hipFree(ix->xnorm);
+    hipFree(ix->stage);
+    hipFree(ix->qpad);
+    hipFree(ix->qnorm);
+    hipFree(ix->partial);
+    hipFree(ix->io);
+    delete ix;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_info(sc_index* ix, int64_t* rows, int32_t* dim, int32_t* ld) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (rows) *rows = ix->n;
+    if (dim) *dim = ix->dim;
+    if (ld) *ld = ix->ld;
+    return SC_OK;
+}
+
+// grow a device scratch buffer (contents not preserved)
+static sc_status grow(sc_index* ix, void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return SC_OK;
+    SC_HIP(hipStreamSynchronize(ix->rt->stream));
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    *cap = need;
+    return SC_OK;
+}
+
+// make room for `rows` rows, preserving the first ix->n
+static sc_status ensure_rows(sc_index* ix, int64_t rows, bool exact) {
+    if (rows <= ix->capacity) return SC_OK;
+    int64_t cap = rows;
+    if (!exact) cap = std::max<int64_t>(rows, std::max<int64_t>(ix->capacity * 2, 4096));
+    float *nx = nullptr, *nn = nullptr;
+    hipError_t e = hipMalloc((void**)&nx, (size_t)cap * ix->ld * sizeof(float));
+    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc corpus (%lld rows x %d) failed: %s", (long long)cap, ix->ld, hipGetErrorString(e));
+    e = hipMalloc((void**)&nn, (size_t)cap * sizeof(float));
+    if (e != hipSuccess) {
+        hipFree(nx);
+        return sc_fail(SC_ERR_NOMEM, "hipMalloc norms failed: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = ix->rt->stream;
+    if (ix->n > 0) {
+        SC_HIP(hipMemcpyAsync(nx, ix->X, (size_t)ix->n * ix->ld * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SC_HIP(hipMemcpyAsync(nn, ix->xnorm, (size_t)ix->n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    SC_HIP(hipStreamSynchronize(s));
+    hipFree(ix->X);
+    hipFree(ix->xnorm);
+    ix->X = nx;
+    ix->xnorm = nn;
+    ix->capacity = cap;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_reserve(sc_index* ix, int64_t rows) {
+    if (!ix || rows < 0) return sc_fail(SC_ERR_INVALID, "sc_index_reserve: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    return ensure_rows(ix, rows, true);
+}
+
+static const int64_t STAGE_ROWS_BYTES = 64ll << 20;
+
+extern "C" sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n) {
+    if (!ix || n < 0 || (n > 0 && !vecs)) return sc_fail(SC_ERR_INVALID, "sc_index_add: bad argument");
+    if (n == 0) return SC_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    if (ix->n + n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "sc_index_add: more than 2^32 rows per shard");
+    sc_status st = ensure_rows(ix, ix->n + n, false);
+    if (st) return st;
+    const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4));
+    hipStream_t s = ix->rt->stream;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        st = grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
+        if (st) return st;
+        SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
+        sc_launch_ingest_rows((const float*)ix->stage, nullptr, ix->n + off, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
+        SC_HIP(hipGetLastError());
+        SC_HIP(hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+    }
+    ix->n += n;
+    ix->trained = false;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n) {
+    if (!ix || n < 0 || (n > 0 && (!vecs || !rows))) return sc_fail(SC_ERR_INVALID, "sc_index_overwrite: bad argument");
+    if (n == 0) return SC_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    for (int64_t i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= ix->n) return sc_fail(SC_ERR_INVALID, "sc_index_overwrite: row %lld out of range [0,%lld)", (long long)rows[i], (long long)ix->n);
+    const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4 + 8));
+    hipStream_t s = ix->rt->stream;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        const size_t vbytes = ((size_t)m * ix->dim * 4 + 15) & ~(size_t)15;
+        sc_status st = grow(ix, (void**)&ix->stage, &ix->stage_cap, vbytes + (size_t)m * 8);
+        if (st) return st;
+        int64_t* drows = (int64_t*)((char*)ix->stage + vbytes);
+        SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
+        SC_HIP(hipMemcpyAsync(drows, rows + off, (size_t)m * 8, hipMemcpyHostToDevice, s));
+        sc_launch_ingest_rows((const float*)ix->stage, drows, 0, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
+        SC_HIP(hipGetLastError());
+        SC_HIP(hipStreamSynchronize(s));
+    }
+    ix->trained = false;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, float* out) {
+    if (!ix || n < 0 || first < 0 || (n > 0 && !out)) return sc_fail(SC_ERR_INVALID, "sc_index_get_rows: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (first + n > ix->n) return sc_fail(SC_ERR_INVALID, "sc_index_get_rows: [%lld,%lld) exceeds %lld rows", (long long)first, (long long)(first + n), (long long)ix->n);
+    if (n == 0) return SC_OK;
+    SC_HIP(hipSetDevice(ix->rt->device));
+    const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4));
+    hipStream_t s = ix->rt->stream;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        sc_status st = grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
+        if (st) return st;
+        sc_launch_gather_rows(ix->X, ix->ld, first + off, m, ix->dim, (float*)ix->stage, s);
+        SC_HIP(hipGetLastError());
+        SC_HIP(hipMemcpyAsync(out + off * ix->dim, ix->stage, (size_t)m * ix->dim * 4, hipMemcpyDeviceToHost, s));
+        SC_HIP(hipStreamSynchronize(s));
+    }
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t seed, int64_t first_row) {
+    if (!ix || n < 0) return sc_fail(SC_ERR_INVALID, "sc_index_fill_synthetic: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    if (n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    ix->n = 0;  // nothing to preserve
+    sc_status st = ensure_rows(ix, n, true);
+    if (st) return st;
+    sc_launch_synth_fill(ix->X, n, ix->dim, ix->ld, seed, first_row, ix->xnorm, ix->rt->stream);
+    SC_HIP(hipGetLastError());
+    ix->n = n;
+    ix->trained = false;
+    return SC_OK;
+}
+
+// q_dev: tight [Q, dim] device; outputs device.  Caller holds ix->mu.
+static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+                                   int64_t* out_rows) {
+    (void)nprobe;
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    ScanPlan plan;
+    if (!sc_scan_exact_plan(ix->ld, Q, k, rt->cus, &plan))
+        return sc_fail(SC_ERR_UNSUPPORTED, "search: k=%d (1..1024) / dim=%d not supported by the exact scan", k, ix->dim);
+    sc_status st = grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
+    if (st) return st;
+    st = grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    if (st) return st;
+    st = grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>(plan.partial_bytes, 16));
+    if (st) return st;
+    sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ix->ld, ix->qnorm, s);
+    int lists = 0;
+    if (ix->n > 0) {
+        hipEvent_t e0, e1;
+        sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+        sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, Q, k, plan, ix->partial, s);
+        sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+        lists = plan.lists;
+    }
+    {
+        hipEvent_t e0, e1;
+        sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+        sc_launch_topk_merge((int)ix->metric, ix->partial, plan.groups, lists, plan.qt, Q, k, ix->row_base, out_dist, out_rows, s);
+        sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+    }
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+static sc_status check_search_args(sc_index* ix, const void* q, int32_t Q, int32_t k, const void* od, const void* orow) {
+    if (!ix || !q || !od || !orow) return sc_fail(SC_ERR_INVALID, "search: NULL argument");
+    if (Q < 1 || Q > (1 << 20)) return sc_fail(SC_ERR_INVALID, "search: Q=%d out of range", Q);
+    if (k < 1) return sc_fail(SC_ERR_INVALID, "search: top_k must be >= 1 (got %d)", k);
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_search_dev(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist_dev,
+                                         int64_t* out_rows_dev) {
+    sc_status st = check_search_args(ix, q_dev, Q, k, out_dist_dev, out_rows_dev);
+    if (st) return st;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    return search_dev_locked(ix, q_dev, Q, k, nprobe, out_dist_dev, out_rows_dev);
+}
+
+extern "C" sc_status sc_index_search(sc_index* ix, const float* q, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+                                     int64_t* out_rows) {
+    sc_status st = check_search_args(ix, q, Q, k, out_dist, out_rows);
+    if (st) return st;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    hipStream_t s = ix->rt->stream;
+    const size_t qb = ((size_t)Q * ix->dim * 4 + 15) & ~(size_t)15;
+    const size_t db = ((size_t)Q * k * 4 + 15) & ~(size_t)15;
+    const size_t rb = (size_t)Q * k * 8;
+    st = grow(ix, (void**)&ix->io, &ix->io_cap, qb + db + rb);
+    if (st) return st;
+    float* dq = (float*)ix->io;
+    float* dd = (float*)((char*)ix->io + qb);
+    int64_t* dr = (int64_t*)((char*)ix->io + qb + db);
+    SC_HIP(hipMemcpyAsync(dq, q, (size_t)Q * ix->dim * 4, hipMemcpyHostToDevice, s));
+    st = search_dev_locked(ix, dq, Q, k, nprobe, dd, dr);
+    if (st) return st;
+    SC_HIP(hipMemcpyAsync(out_dist, dd, (size_t)Q * k * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipMemcpyAsync(out_rows, dr, (size_t)Q * k * 8, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------ host merge of per-shard results
+
+extern "C" sc_status sc_topk_merge_host(sc_metric metric, int32_t lists, int32_t Q, int32_t k, const float* dist, const int64_t* rows,
+                                        float* out_dist, int64_t* out_rows) {
+    if (lists < 1 || Q < 1 || k < 1 || !dist || !rows || !out_dist || !out_rows) return sc_fail(SC_ERR_INVALID, "sc_topk_merge_host: bad argument");
+    struct Ent { uint32_t u; int64_t row; float d; };
+    std::vector<Ent> v;
+    v.reserve((size_t)lists * k);
+    for (int q = 0; q < Q; ++q) {
+        v.clear();
+        for (int l = 0; l < lists; ++l)
+            for (int j = 0; j < k; ++j) {
+                const size_t o = ((size_t)l * Q + q) * k + j;
+                if (rows[o] < 0) continue;
+                float x = (metric == SC_METRIC_L2) ? dist[o] : -dist[o];
+                x = x + 0.0f;
+                uint32_t u;
+                memcpy(&u, &x, 4);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                v.push_back({u, rows[o], dist[o]});
+            }
+        std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.u != b.u ? a.u < b.u : a.row < b.row; });
+        for (int j = 0; j < k; ++j) {
+            const size_t o = (size_t)q * k + j;
+            if (j < (int)v.size()) {
+                out_dist[o] = v[j].d;
+                out_rows[o] = v[j].row;
+            } else {
+                out_dist[o] = (metric == SC_METRIC_L2) ? INFINITY : -INFINITY;
+                out_rows[o] = -1;
+            }
+        }
+    }
+    return SC_OK;
+}

@@ -1,0 +1,83 @@
+// sc_common.h -- shared host/device definitions for libsemcode_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/semcode_hip.h"
+
+#define SC_WAVE 64
+#define SC_LD_ALIGN 64            // corpus row stride is a multiple of 64 floats (256 B)
+#define SC_KEY_MAX 0xFFFFFFFFFFFFFFFFull
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ static inline uint64_t sc_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Irwin-Hall(12) integer-hash N(0,1) approximation; bit-exact twin: oracle/sc_oracle.c sc_oracle_synth.
+__host__ __device__ static inline float sc_synth_value(uint64_t key, uint64_t row, uint32_t col, uint32_t dim) {
+    const uint64_t ctr = (row * (uint64_t)dim + col) * 3ull;
+    int32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        uint64_t h = sc_mix64(key ^ ((ctr + (uint64_t)j) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+        sum += (int32_t)(h & 0xFFFF) + (int32_t)((h >> 16) & 0xFFFF) + (int32_t)((h >> 32) & 0xFFFF) + (int32_t)(h >> 48);
+    }
+    return (float)(sum - 393210) * (1.0f / 65536.0f);
+}
+__host__ __device__ static inline uint64_t sc_synth_key(uint64_t seed) { return sc_mix64(seed + 0x9E3779B97F4A7C15ull); }
+
+// score from the exact dot product and the two squared norms (metric: sc_metric)
+template <int METRIC>
+__host__ __device__ static inline float sc_score(float dot, float xn, float qn) {
+    if (METRIC == SC_METRIC_L2) return fmaf(-2.0f, dot, xn + qn);
+    if (METRIC == SC_METRIC_COSINE) return dot / (sqrtf(xn) * sqrtf(qn));
+    return dot;
+}
+
+// 64-bit total order, smaller = better: (order-preserving float map of +-score) << 32 | row
+template <int METRIC>
+__host__ __device__ static inline uint64_t sc_make_key(float score, uint32_t row) {
+    float v = (METRIC == SC_METRIC_L2) ? score : -score;
+    v = v + 0.0f;
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | row;
+}
+__host__ __device__ static inline float sc_key_score(int metric, uint64_t key) {
+    uint32_t u = (uint32_t)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float v = __builtin_bit_cast(float, u);
+    return (metric == SC_METRIC_L2) ? v : -v;
+}
+
+// ---- launchers implemented in the .hip files (all enqueue on `s`, never synchronise) ----
+
+// rows.hip: out [rows, ld] synthetic (+ optional |x|^2); tight [n, dim] -> padded rows (+ |x|^2); rows -> tight
+void sc_launch_synth_fill(float* out, int64_t rows, int dim, int ld, uint64_t seed, int64_t first_row, float* xnorm, hipStream_t s);
+void sc_launch_ingest_rows(const float* src, const int64_t* rows, int64_t first, int64_t n, int dim, float* dst, int ld,
+                           float* xnorm, hipStream_t s);
+void sc_launch_gather_rows(const float* src, int ld, int64_t first, int64_t n, int dim, float* dst, hipStream_t s);
+
+struct ScanPlan {
+    int qt;          // queries per group (<=16)
+    int groups;      // ceil(Q / qt)
+    int nwg;         // workgroups per group (grid.x)
+    int cap;         // per-(wave,query) candidate capacity
+    int lists;       // partial lists per query = nwg * 4
+    size_t lds;      // dynamic LDS bytes
+    size_t partial_bytes;
+};
+// returns false when (ld, k) cannot be served by the exact kernel
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p);
+// X [n, ld], xnorm [n]; Qp [Q, ld] zero padded, qnorm [Q]; partial: plan.partial_bytes
+void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp,
+                          const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, hipStream_t s);
+// partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
+void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k,
+                          int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);

@@ -1,0 +1,275 @@
+// scan_exact.hip -- exact f32 distance scan fused with per-wave top-k (gfx950 / CDNA4).
+//
+// Replaces (reference): the server side of Collection.search(...) for a FLAT scan,
+// src/semcode/storage/milvus_store.py:141-147 (one query per call there; up to 16 per pass here).
+//
+// Roofline: HBM.  Algorithmic bytes = n * dim * 4 per pass of <= qt queries; the arithmetic
+// (v_mfma_f32_16x16x4_f32, 32 cycles per 64 corpus floats per SIMD) sustains ~19 TB/s chip-wide, so
+// for <= 16 queries the corpus stream is the only bound.
+//
+// Structure (one workgroup = 4 independent waves, 1 workgroup per CU):
+//   * each wave owns 16-row tiles of a contiguous row range; a tile is streamed as ld/64 stages of
+//     16 rows x 64 floats (4 KiB) by LDS-DMA (global_load_lds_dwordx4, four 1 KiB pieces per stage)
+//     into a private 4-deep LDS ring -- no barrier in the loop, ordering by counted s_waitcnt vmcnt;
+//   * the LDS image is XOR-swizzled through the per-lane SOURCE address (LDS-DMA writes linearly):
+//     16-byte chunk ch of row r lives in slot ch ^ r, which makes the ds_read_b128 A-fragment reads
+//     conflict free;
+//   * the <= 16 queries sit in LDS for the whole kernel (row pad 32 B -> conflict-free B reads);
+//   * MFMA: A = corpus (row = lane & 15, k-group = lane >> 4), B = queries (col = lane & 15), one
+//     fmaf chain per (row, query) in the canonical k order of oracle/sc_oracle.c sc_oracle_dot;
+//   * per tile each lane holds 4 scores of one query: threshold filter against the wave's running
+//     k-th best key, rare LDS append, rank-sort compaction when a candidate buffer fills;
+//   * each wave writes its sorted k best keys per query; topk_merge.hip reduces the lists.
+#include "sc_common.h"
+
+#define SCAN_WAVES 4
+#define SCAN_NSTAGE 4
+#define SCAN_STAGE_BYTES 4096
+#define SCAN_NORM_BYTES 256
+#define SCAN_QPAD 8  // floats
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+// volatile accesses must carry the LDS address space explicitly: address-space inference skips
+// volatile operations, and a FLAT access counts on vmcnt, which would drain the LDS-DMA ring.
+typedef __attribute__((address_space(3))) volatile uint64_t* lds_u64p;
+typedef __attribute__((address_space(3))) volatile unsigned* lds_u32p;
+
+struct ScanArgs {
+    const float* X;
+    const float* xnorm;
+    int64_t n;
+    int ld;
+    const float* Qp;
+    const float* qnorm;
+    int Q;
+    int qt;
+    int k;
+    int cap;
+    int tiles_per_wg;
+    uint64_t* partial;
+};
+
+struct ScanLds {
+    unsigned ring, norms, qs, qn, thr, cnt, cand, tmp, total;
+};
+__host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int cap) {
+    ScanLds L;
+    unsigned o = 0;
+    L.ring = o; o += SCAN_WAVES * SCAN_NSTAGE * SCAN_STAGE_BYTES;
+    L.norms = o; o += SCAN_WAVES * SCAN_NSTAGE * SCAN_NORM_BYTES;
+    L.qs = o; o += (unsigned)qt * (unsigned)(ld + SCAN_QPAD) * 4u;
+    L.qn = o; o += 64;
+    L.thr = o; o += SCAN_WAVES * 16 * 8;
+    L.cnt = o; o += SCAN_WAVES * 16 * 4;
+    L.cand = o; o += (unsigned)SCAN_WAVES * (unsigned)qt * (unsigned)cap * 8u;
+    L.tmp = o; o += (unsigned)SCAN_WAVES * (unsigned)cap * 8u;
+    L.total = o;
+    return L;
+}
+
+// Rank-sort the n (<= cap) candidate keys of one query slot, keep the k smallest in order, and
+// refresh the pruning threshold.  Executed by one whole wave; all traffic through volatile LDS.
+static __device__ __forceinline__ void wave_compact(lds_u64p cand, lds_u64p tmp, lds_u32p cnt, lds_u64p thr, int k, int lane) {
+    const int n = (int)*cnt;
+    for (int e = lane; e < n; e += 64) {
+        const uint64_t key = cand[e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (cand[j] < key) ? 1 : 0;
+        if (rank < k) tmp[rank] = key;
+    }
+    const int m = n < k ? n : k;
+    for (int e = lane; e < m; e += 64) cand[e] = tmp[e];
+    if (lane == 0) {
+        *cnt = (unsigned)m;
+        if (n >= k) *thr = tmp[k - 1];
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15;  // A row / B column (query slot)
+    const int g = lane >> 4;    // k-group
+    const ScanLds L = scan_lds_layout(a.ld, a.qt, a.cap);
+    const int ld = a.ld;
+    const int spt = ld >> 6;  // stages per tile
+    const int grp = blockIdx.y;
+    const int q0 = grp * a.qt;
+    const int nq = min(a.qt, a.Q - q0);
+
+    // ---- queries -> LDS (once), thresholds / counters
+    {
+        const int qstride = ld + SCAN_QPAD;
+        float* qs = reinterpret_cast<float*>(smem + L.qs);
+        for (int c = 0; c < a.qt; ++c) {
+            const bool have = c < nq;
+            const float* src = a.Qp + (int64_t)(q0 + (have ? c : 0)) * ld;
+            for (int kk = tid * 4; kk < ld; kk += 1024) {
+                f32x4 v = have ? *reinterpret_cast<const f32x4*>(src + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(qs + c * qstride + kk) = v;
+            }
+        }
+        if (tid < 16) reinterpret_cast<float*>(smem + L.qn)[tid] = (tid < nq) ? a.qnorm[q0 + tid] : 1.0f;
+        if (tid < SCAN_WAVES * 16) {
+            reinterpret_cast<uint64_t*>(smem + L.thr)[tid] = SC_KEY_MAX;
+            reinterpret_cast<unsigned*>(smem + L.cnt)[tid] = 0u;
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's tiles: wg range [t0, t1), wave takes t0 + w, t0 + w + 4, ...
+    const int64_t total_tiles = (a.n + 15) >> 4;
+    const int64_t t0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+    int64_t t1 = t0 + a.tiles_per_wg;
+    if (t1 > total_tiles) t1 = total_tiles;
+    int ntiles = 0;
+    if (t0 + w < t1) ntiles = (int)((t1 - (t0 + w) + SCAN_WAVES - 1) / SCAN_WAVES);
+    const int total_stages = ntiles * spt;
+
+    char* ring = smem + L.ring + w * (SCAN_NSTAGE * SCAN_STAGE_BYTES);
+    char* nrm = smem + L.norms + w * (SCAN_NSTAGE * SCAN_NORM_BYTES);
+    const char* qsb = smem + L.qs + (size_t)(r16 < a.qt ? r16 : a.qt - 1) * (size_t)(ld + SCAN_QPAD) * 4u + (size_t)g * 16u;
+    lds_u64p thr_w = (lds_u64p)(smem + L.thr) + w * 16;
+    lds_u32p cnt_w = (lds_u32p)(smem + L.cnt) + w * 16;
+    lds_u64p cand_w = (lds_u64p)(smem + L.cand) + w * a.qt * a.cap;
+    lds_u64p tmp_w = (lds_u64p)(smem + L.tmp) + w * a.cap;
+    const float qn_mine = reinterpret_cast<const float*>(smem + L.qn)[r16];
+    const int64_t last_row = a.n - 1;
+
+    // issue side: (tile ordinal, k-chunk) of the next stage to request
+    int iss = 0, iss_tile = 0, iss_kc = 0;
+    // per-lane source geometry of one LDS-DMA piece: row-in-piece = lane>>4, slot = lane&15
+    const int prow = lane >> 4, pslot = lane & 15;
+
+    auto issue_stage = [&]() {
+        const int64_t row0 = (t0 + w + (int64_t)iss_tile * SCAN_WAVES) << 4;
+        const int slot = iss & (SCAN_NSTAGE - 1);
+        if (iss_kc == 0) {  // tile norms first: older than the tile's data in the vmcnt queue
+            int64_t rr = row0 + r16;
+            rr = rr > last_row ? last_row : rr;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(a.xnorm + rr), (lds_vptr)(nrm + (iss_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES),
+                                             4, 0, 0);
+        }
+        char* dst = ring + slot * SCAN_STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 4 * p + prow;
+            int64_t rr = row0 + r;
+            rr = rr > last_row ? last_row : rr;
+            const float* src = a.X + rr * (int64_t)ld + (iss_kc << 6) + ((pslot ^ r) << 2);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(dst + p * 1024), 16, 0, 0);
+        }
+        ++iss;
+        if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
+    };
+
+#pragma unroll 1
+    for (int j = 0; j < SCAN_NSTAGE - 1; ++j)
+        if (iss < total_stages) issue_stage();
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int con_tile = 0, con_kc = 0;
+#pragma unroll 1
+    for (int si = 0; si < total_stages; ++si) {
+        if (iss < total_stages) issue_stage();
+        // younger stages in flight behind stage si: each is >= 4 LDS-DMA instructions
+        const int pend = iss - si - 1;
+        if (pend >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (pend == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (pend == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        const char* st = ring + (si & (SCAN_NSTAGE - 1)) * SCAN_STAGE_BYTES + r16 * 256;
+        const char* qb = qsb + (size_t)con_kc * 256u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(st + (((4 * t + g) ^ r16) << 4));
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(qb + t * 64);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+        }
+
+        if (++con_kc == spt) {
+            // ---- tile done: lane holds query r16, rows row0 + 4g + {0..3}
+            const int64_t row0 = (t0 + w + (int64_t)con_tile * SCAN_WAVES) << 4;
+            const f32x4 xn = *reinterpret_cast<const f32x4*>(nrm + (con_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES + g * 16);
+            const uint64_t thr = thr_w[r16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t row = row0 + 4 * g + c;
+                const float sc = sc_score<METRIC>(acc[c], xn[c], qn_mine);
+                const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
+                if (r16 < nq && row <= last_row && key < thr) {
+                    // inline asm: a compiler-visible LDS write here would get an s_waitcnt vmcnt(0) in front
+                    // of it (it may alias the in-flight LDS-DMA as far as hipcc knows) and drain the ring.
+                    unsigned pos;
+                    const unsigned cnt_addr = (unsigned)(uintptr_t)(cnt_w + r16), one = 1u;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(cnt_addr), "v"(one) : "memory");
+                    const unsigned slot_addr = (unsigned)(uintptr_t)(cand_w + r16 * a.cap + pos);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(slot_addr), "v"(key) : "memory");
+                }
+            }
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool full = cnt_w[r16] > (unsigned)(a.cap - 16);
+            if (__any(full)) {
+                for (int c = 0; c < nq; ++c)
+                    if (cnt_w[c] > (unsigned)(a.cap - 16))
+                        wave_compact(cand_w + c * a.cap, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+            }
+            con_kc = 0;
+            ++con_tile;
+        }
+    }
+
+    // ---- flush: sorted k best per query slot -> partial[grp][wg*4 + w][slot][k]
+    uint64_t* out = a.partial + (((size_t)grp * gridDim.x + blockIdx.x) * SCAN_WAVES + w) * (size_t)a.qt * a.k;
+    for (int c = 0; c < a.qt; ++c) {
+        int m = 0;
+        if (c < nq) {
+            wave_compact(cand_w + c * a.cap, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+            m = (int)cnt_w[c];
+        }
+        for (int e = lane; e < a.k; e += 64) out[(size_t)c * a.k + e] = e < m ? cand_w[c * a.cap + e] : SC_KEY_MAX;
+    }
+}
+
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p) {
+    if (ld <= 0 || (ld % SC_LD_ALIGN) != 0 || k < 1 || k > 1024 || Q < 1) return false;
+    const int cap = ((k + 16 + 63) / 64) * 64;  // >= k + 16, multiple of 64
+    const unsigned budget = 160 * 1024;
+    int qt = Q < 16 ? Q : 16;
+    while (qt >= 1 && scan_lds_layout(ld, qt, cap).total > budget) --qt;
+    if (qt < 1) return false;
+    p->qt = qt;
+    p->groups = (Q + qt - 1) / qt;
+    p->nwg = cus > 0 ? cus : 256;
+    p->cap = cap;
+    p->lists = p->nwg * SCAN_WAVES;
+    p->lds = scan_lds_layout(ld, qt, cap).total;
+    p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t);
+    return true;
+}
+
+void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp, const float* qnorm,
+                          int Q, int k, const ScanPlan& p, uint64_t* partial, hipStream_t s) {
+    ScanArgs a;
+    a.X = X; a.xnorm = xnorm; a.n = n; a.ld = ld; a.Qp = Qp; a.qnorm = qnorm; a.Q = Q; a.qt = p.qt; a.k = k; a.cap = p.cap;
+    const int64_t tiles = (n + 15) / 16;
+    a.tiles_per_wg = (int)((tiles + p.nwg - 1) / p.nwg);
+    a.partial = partial;
+    dim3 grid((unsigned)p.nwg, (unsigned)p.groups), block(256);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_L2>, grid, block, p.lds, s, a);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_COSINE>, grid, block, p.lds, s, a);
+    else hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_IP>, grid, block, p.lds, s, a);
+}
