@@ -9,6 +9,7 @@ Parity status: "parity unpinned" at the third-party boundary (see the header of 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import shutil
 import subprocess
 from pathlib import Path
@@ -59,6 +60,15 @@ def lib() -> C.CDLL:
         h.sc_oracle_search_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                             C.c_void_p, C.c_void_p]
         h.sc_oracle_threads.restype = C.c_int32
+        h.sc_oracle_synth_rows.restype = None
+        h.sc_oracle_synth_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64]
+        h.sc_oracle_set_threads.restype = None
+        h.sc_oracle_set_threads.argtypes = [C.c_int32]
+        # never more OpenMP threads than CPUs this process may run on (cgroup-limited GPU boxes)
+        try:
+            h.sc_oracle_set_threads(max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 32)))
+        except AttributeError:  # pragma: no cover
+            pass
         _lib = h
     return _lib
 
@@ -88,11 +98,9 @@ def synth(rows: int, dim: int, seed: int, first_row: int = 0, ld: int | None = N
 
 def synth_rows(rows_idx, dim: int, seed: int) -> np.ndarray:
     """Regenerate arbitrary (global) rows of the synthetic corpus: random access, no storage."""
-    rows_idx = np.asarray(rows_idx, dtype=np.int64)
+    rows_idx = np.ascontiguousarray(rows_idx, dtype=np.int64)
     out = np.empty((len(rows_idx), dim), dtype=np.float32)
-    h = lib()
-    for i, r in enumerate(rows_idx):
-        h.sc_oracle_synth_fill(out[i].ctypes.data_as(C.c_void_p), 1, dim, dim, seed, int(r))
+    lib().sc_oracle_synth_rows(out.ctypes.data_as(C.c_void_p), rows_idx.ctypes.data_as(C.c_void_p), len(rows_idx), dim, seed)
     return out
 
 
