@@ -1,0 +1,243 @@
+"""MilvusVectorStore drop-in backed by the HBM-resident index of libsemcode_hip.
+
+Reference: src/semcode/storage/milvus_store.py:29-148.  Same constructor, attributes, methods,
+progress protocol and error behaviour, so IndexerService (src/semcode/services/indexer.py:54-63,
+108) and SemanticSearchPipeline (src/semcode/rag/pipeline.py:93-169) run on it unchanged:
+
+    MilvusVectorStore(collection_name="semcode_chunks", dim=None)
+    .connect()                                  -> opens the device runtime + index (was: gRPC connect,
+                                                   create collection + IVF_FLAT/IP index, load)
+    .upsert_embeddings(payloads, progress=None) -> replace-by-primary-key, batches of
+                                                   settings.milvus_upsert_batch_size
+    .search(vector, top_k=10)                   -> iterable of Hits; hit.entity.get(field), hit.distance,
+                                                   hit.score, hit.id  (pymilvus SearchResult shape)
+
+What lives where: vectors and their norms in HBM (sc_index); the scalar columns of the reference
+schema (id, repo, path, language, text, metadata; milvus_store.py:59-74) and the md5 -> row map in
+this object.  Additions that do not break the reference surface: search_batch(), metric/index options.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+from typing import Any, Callable, Iterator, List, Optional, Sequence
+
+import numpy as np
+
+from ..embeddings.payload import EmbeddingPayload
+from ..settings import resolve as _resolve_settings
+
+log = logging.getLogger(__name__)
+
+OUTPUT_FIELDS = ("repo", "path", "language", "text", "metadata")  # milvus_store.py:146
+
+
+class _Entity:
+    """pymilvus Hit.entity look-alike: .get(name) over the stored scalar columns."""
+
+    __slots__ = ("_fields",)
+
+    def __init__(self, fields: dict) -> None:
+        self._fields = fields
+
+    def get(self, name: str, default: Any = None) -> Any:
+        return self._fields.get(name, default)
+
+    def to_dict(self) -> dict:
+        return dict(self._fields)
+
+
+class Hit:
+    """One search hit: .id (primary key), .distance == .score (metric value), .entity.get(field)."""
+
+    __slots__ = ("id", "distance", "entity", "row")
+
+    def __init__(self, pk: str, distance: float, fields: dict, row: int) -> None:
+        self.id = pk
+        self.distance = float(distance)
+        self.entity = _Entity(fields)
+        self.row = row
+
+    @property
+    def score(self) -> float:
+        return self.distance
+
+    def __repr__(self) -> str:  # pragma: no cover
+        return f"Hit(id={self.id!r}, distance={self.distance:.6g})"
+
+
+class Hits(list):
+    """Per-query hit list, best first (pymilvus Hits)."""
+
+    @property
+    def ids(self) -> list:
+        return [h.id for h in self]
+
+    @property
+    def distances(self) -> list:
+        return [h.distance for h in self]
+
+
+class SearchResult(list):
+    """List of Hits, one per query; `next(iter(result))` is what pipeline.py:117-118 does."""
+
+
+class MilvusVectorStore:
+    """Thin wrapper with the reference's surface, storing vectors on the MI355X."""
+
+    def __init__(self, collection_name: str = "semcode_chunks", dim: Optional[int] = None, *, metric: Optional[str] = None,
+                 index_type: Optional[str] = None, nlist: Optional[int] = None, nprobe: Optional[int] = None,
+                 device: Optional[int] = None, runtime: Any = None, index_factory: Optional[Callable[..., Any]] = None) -> None:
+        settings = _resolve_settings()
+        self.collection_name = collection_name
+        self.dim = dim or settings.embedding_dimension
+        self._collection: Any = None  # the device index once connected (name kept from the reference)
+        self.metric = (metric or getattr(settings, "mi355x_metric", "IP")).upper()
+        self.index_type = (index_type or getattr(settings, "mi355x_index_type", "IVF_FLAT")).upper()
+        self.nlist = int(nlist or getattr(settings, "mi355x_nlist", 128))
+        self.nprobe = int(nprobe or getattr(settings, "mi355x_nprobe", 16))
+        self._device = int(device if device is not None else getattr(settings, "mi355x_device", 0))
+        self._runtime = runtime
+        self._owns_runtime = runtime is None
+        self._index_factory = index_factory
+        self._lock = threading.RLock()
+        # scalar columns, indexed by row (milvus_store.py:59-74)
+        self._ids: List[str] = []
+        self._texts: List[str] = []
+        self._metadata: List[dict] = []
+        self._repos: List[str] = []
+        self._paths: List[str] = []
+        self._languages: List[str] = []
+        self._row_of: dict[str, int] = {}
+
+    # ------------------------------------------------------------------ lifecycle
+    def connect(self) -> None:
+        """Open the device and create the (empty) collection.  May raise; callers catch Exception."""
+        settings = _resolve_settings()
+        log.info("connecting_mi355x device=%s (milvus_uri %s is not used)", self._device, getattr(settings, "milvus_uri", None))
+        with self._lock:
+            if self._collection is not None:
+                return
+            self._collection = self._ensure_collection()
+
+    def _ensure_collection(self) -> Any:
+        if self._index_factory is not None:
+            return self._index_factory(dim=self.dim, metric=self.metric, kind=self.index_type, nlist=self.nlist)
+        from .. import _native  # raises loudly if libsemcode_hip.so is missing
+
+        if self._runtime is None:
+            self._runtime = _native.Runtime(device=self._device)
+        log.info("creating_collection %s dim=%d metric=%s index=%s", self.collection_name, self.dim, self.metric, self.index_type)
+        return _native.Index(self._runtime, self.dim, metric=self.metric, kind=self.index_type, nlist=self.nlist)
+
+    def close(self) -> None:
+        with self._lock:
+            if self._collection is not None and hasattr(self._collection, "close"):
+                self._collection.close()
+            self._collection = None
+            if self._owns_runtime and self._runtime is not None:
+                self._runtime.close()
+                self._runtime = None
+
+    def __len__(self) -> int:
+        return len(self._ids)
+
+    # ------------------------------------------------------------------ upsert
+    def upsert_embeddings(self, payloads: Sequence[EmbeddingPayload], progress: Optional[Callable[[int, int], None]] = None) -> None:
+        """Insert or update embeddings (replace by primary key), reference milvus_store.py:87-133."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+
+        payload_list: List[EmbeddingPayload] = list(payloads)
+        total = len(payload_list)
+        log.info("upserting_embeddings count=%d", total)
+        if progress:
+            progress(0, total)
+        if total == 0:
+            return
+
+        settings = _resolve_settings()
+        batch_size = max(1, getattr(settings, "milvus_upsert_batch_size", 128))
+        inserted = 0
+        for start in range(0, total, batch_size):
+            batch = payload_list[start:start + batch_size]
+            with self._lock:
+                self._upsert_batch(batch)
+            inserted += len(batch)
+            if progress:
+                progress(inserted, total)
+
+    def _upsert_batch(self, batch: Sequence[EmbeddingPayload]) -> None:
+        vectors = np.asarray([p.vector for p in batch], dtype=np.float32)
+        if vectors.ndim != 2 or vectors.shape[1] != self.dim:
+            raise ValueError(f"embedding dimension mismatch: collection dim={self.dim}, got array of shape {vectors.shape}")
+        # a primary key repeated inside one batch: the last occurrence wins (upsert semantics)
+        last = {p.id: i for i, p in enumerate(batch)}
+        new_idx, new_rows, old_idx, old_rows = [], [], [], []
+        next_row = len(self._ids)
+        for pk, i in last.items():
+            row = self._row_of.get(pk)
+            if row is None:
+                new_idx.append(i)
+                new_rows.append(next_row)
+                next_row += 1
+            else:
+                old_idx.append(i)
+                old_rows.append(row)
+        order = np.argsort(new_idx) if new_idx else []
+        new_idx = [new_idx[j] for j in order]
+        if new_idx:
+            self._collection.add(vectors[new_idx])
+        if old_idx:
+            self._collection.overwrite(vectors[old_idx], np.asarray(old_rows, dtype=np.int64))
+        for i in new_idx:
+            p = batch[i]
+            self._row_of[p.id] = len(self._ids)
+            self._ids.append(p.id)
+            self._repos.append(p.metadata.get("repo", ""))
+            self._paths.append(p.metadata.get("path", ""))
+            self._languages.append(p.metadata.get("language", ""))
+            self._texts.append(p.text)
+            self._metadata.append(p.metadata)
+        for i, row in zip(old_idx, old_rows):
+            p = batch[i]
+            self._repos[row] = p.metadata.get("repo", "")
+            self._paths[row] = p.metadata.get("path", "")
+            self._languages[row] = p.metadata.get("language", "")
+            self._texts[row] = p.text
+            self._metadata[row] = p.metadata
+
+    # ------------------------------------------------------------------ search
+    def search(self, vector: "list[float]", top_k: int = 10) -> SearchResult:
+        """Run a raw vector search (one query), reference milvus_store.py:135-148."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        dist, rows = self.search_batch(np.asarray([vector], dtype=np.float32), top_k)
+        return SearchResult([self._hits(dist[0], rows[0])])
+
+    def search_batch(self, queries: Any, top_k: int = 10) -> "tuple[np.ndarray, np.ndarray]":
+        """Batched search: queries [Q, dim] -> (dist [Q, k] f32, rows [Q, k] i64; -1 = no hit), best first."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        q = np.asarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: collection dim={self.dim}, got shape {q.shape}")
+        with self._lock:
+            return self._collection.search(q, k=int(top_k), nprobe=self.nprobe)
+
+    def hits_for(self, dist: np.ndarray, rows: np.ndarray) -> SearchResult:
+        """Materialise pymilvus-shaped results for a search_batch() output."""
+        return SearchResult([self._hits(d, r) for d, r in zip(dist, rows)])
+
+    def _hits(self, dist: np.ndarray, rows: np.ndarray) -> Hits:
+        hits = Hits()
+        for d, r in zip(dist.tolist(), rows.tolist()):
+            if r < 0:
+                continue
+            fields = {"repo": self._repos[r], "path": self._paths[r], "language": self._languages[r], "text": self._texts[r],
+                      "metadata": self._metadata[r]}
+            hits.append(Hit(self._ids[r], d, fields, r))
+        return hits
+
+    def __iter__(self) -> Iterator:  # pragma: no cover - convenience
+        return iter(self._ids)
