@@ -95,6 +95,46 @@ sc_status sc_runtime_profile_reset(sc_runtime* rt);
 sc_status sc_synth_fill_dev(sc_runtime* rt, float* out, int64_t rows, int32_t dim, int32_t ld,
                             uint64_t seed, int64_t first_row);
 
+/* ------------------------------------------------------------------- encoder ---- */
+
+/* BERT-family post-LN transformer encoder (the "transformer-encoder forward" of BASELINE.json;
+ * BERT-base shape = 30522 / 768 / 12 / 12 / 3072 / 512 / 2, eps 1e-12).  Head dimension must be 64. */
+typedef struct sc_encoder_cfg {
+    int32_t vocab, hidden, layers, heads, ffn, max_pos, type_vocab;
+    float ln_eps;
+    int32_t normalize;    /* 1 = L2-normalise the pooled vector                               */
+    uint64_t synth_seed;  /* used only when no weight blob is given (benchmarks)              */
+} sc_encoder_cfg;
+
+/* Size in bytes of the f32 weight blob sc_encoder_create expects for cfg.  Blob order (all f32,
+ * torch.nn.Linear layout [out, in]): word_emb [vocab,H], pos_emb [max_pos,H], type_emb [type_vocab,H],
+ * emb_ln_gamma [H], emb_ln_beta [H], then per layer: Wq [H,H], bq, Wk, bk, Wv, bv, Wo [H,H], bo,
+ * ln1_gamma, ln1_beta, W1 [ffn,H], b1 [ffn], W2 [H,ffn], b2 [H], ln2_gamma, ln2_beta. */
+sc_status sc_encoder_blob_bytes(const sc_encoder_cfg* cfg, int64_t* out);
+/* Replaces EmbeddingProviderFactory.create() loading a model (providers.py:69-100): uploads the
+ * weights (converted to bf16 on device).  weights_blob == NULL: synthetic weights 0.02*N(0,1) from
+ * cfg.synth_seed, LayerNorm gamma 1 / beta 0, biases 0 (random-init benchmark weights). */
+sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg, const void* weights_blob, size_t nbytes, sc_encoder** out);
+sc_status sc_encoder_destroy(sc_encoder* enc);
+sc_status sc_encoder_info(sc_encoder* enc, sc_encoder_cfg* cfg_out);
+/* Replaces Embeddings.embed_documents / embed_query after tokenisation (indexer.py:150,
+ * pipeline.py:171-175): ids [B,S] int32 (S in {32,64,128,256,512}, padded by the caller), lens [B] =
+ * number of real tokens per row (keys >= len are masked, pooling = mean over the first len tokens),
+ * out [B,hidden] f32.  Host pointers; synchronises. */
+sc_status sc_encoder_embed_ids(sc_encoder* enc, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, float* out);
+/* Same with DEVICE pointers; asynchronous on the runtime's stream. */
+sc_status sc_encoder_embed_ids_dev(sc_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S,
+                                   float* out_dev);
+
+/* Diagnostics: run ONE encoder kernel on host f32 data (rounded to bf16 on device, result widened
+ * back to f32) so that the parity tests can check the GEMM and the attention kernel in isolation.
+ * epi: 0 = bias, 1 = bias + erf-GELU, 2 = bias + residual R [M,N].  out [M,N] = A [M,K] * W [N,K]^T.
+ * M, N multiples of 128, K multiple of 64. */
+sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const float* W, const float* bias, const float* R,
+                            int32_t M, int32_t N, int32_t K, float* out);
+/* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
+sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);
+
 /* -------------------------------------------------------------- vector index ---- */
 
 /* Replaces Collection(...)+create_index(IVF_FLAT, metric, nlist) (milvus_store.py:59-84).

@@ -32,6 +32,12 @@ class _Cfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_int32)]
 
 
+class EncoderCfg(C.Structure):
+    _fields_ = [("vocab", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32),
+                ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("ln_eps", C.c_float), ("normalize", C.c_int32),
+                ("synth_seed", C.c_uint64)]
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -51,6 +57,14 @@ SIGNATURES = {
     "sc_runtime_profile_read": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sc_runtime_profile_reset": (C.c_int32, [C.c_void_p]),
     "sc_synth_fill_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int64]),
+    "sc_encoder_blob_bytes": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64)]),
+    "sc_encoder_create": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sc_encoder_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_encoder_info": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg)]),
+    "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "sc_index_destroy": (C.c_int32, [C.c_void_p]),
     "sc_index_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -227,6 +241,92 @@ class Index:
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
         """Device-pointer variant (asynchronous on the runtime's stream)."""
         _check(lib().sc_index_search_dev(self.handle, C.c_void_p(q_ptr), int(Q), int(k), int(nprobe), C.c_void_p(dist_ptr), C.c_void_p(rows_ptr)))
+
+
+BERT_BASE = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512, type_vocab=2, ln_eps=1e-12)
+SEQ_BUCKETS = (32, 64, 128, 256, 512)
+
+
+class Encoder:
+    """Transformer-encoder forward on the device (sc_encoder): token ids in, pooled f32 vectors out."""
+
+    def __init__(self, rt: Runtime, cfg: dict | None = None, weights: np.ndarray | None = None, normalize: bool = False,
+                 synth_seed: int = 0):
+        c = dict(BERT_BASE)
+        c.update(cfg or {})
+        self.cfg = EncoderCfg(vocab=c["vocab"], hidden=c["hidden"], layers=c["layers"], heads=c["heads"], ffn=c["ffn"],
+                              max_pos=c["max_pos"], type_vocab=c["type_vocab"], ln_eps=c["ln_eps"], normalize=1 if normalize else 0,
+                              synth_seed=synth_seed)
+        self.rt = rt
+        self.hidden = c["hidden"]
+        self.max_pos = c["max_pos"]
+        self._h = C.c_void_p()
+        need = C.c_int64()
+        _check(lib().sc_encoder_blob_bytes(C.byref(self.cfg), C.byref(need)))
+        self.blob_bytes = need.value
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+            _check(lib().sc_encoder_create(rt.handle, C.byref(self.cfg), w.ctypes.data_as(C.c_void_p), w.nbytes, C.byref(self._h)))
+        else:
+            _check(lib().sc_encoder_create(rt.handle, C.byref(self.cfg), None, 0, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().sc_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("encoder is closed")
+        return self._h
+
+    def embed_ids(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
+        """ids [B, S] int32 with S in SEQ_BUCKETS, lens [B] -> [B, hidden] f32."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if ids.ndim != 2 or lens.shape != (ids.shape[0],):
+            raise ValueError("ids must be [B, S] and lens [B]")
+        B, S = ids.shape
+        out = np.empty((B, self.hidden), dtype=np.float32)
+        _check(lib().sc_encoder_embed_ids(self.handle, ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S,
+                                          out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def embed_ids_dev(self, ids_ptr: int, lens_ptr: int, B: int, S: int, out_ptr: int) -> None:
+        _check(lib().sc_encoder_embed_ids_dev(self.handle, C.c_void_p(ids_ptr), C.c_void_p(lens_ptr), int(B), int(S), C.c_void_p(out_ptr)))
+
+
+def diag_gemm_bf16(rt: Runtime, A, W, bias, R=None, epi: int = 0) -> np.ndarray:
+    """One GEMM kernel launch on host data (parity tests): out [M,N] = A [M,K] @ W [N,K].T (+ epilogue)."""
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), np.float32)
+    Rp = None
+    if R is not None:
+        R = np.ascontiguousarray(R, np.float32)
+        Rp = R.ctypes.data_as(C.c_void_p)
+    _check(lib().sc_diag_gemm_bf16(rt.handle, epi, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
+                                   bias.ctypes.data_as(C.c_void_p), Rp, M, N, K, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def diag_attention(rt: Runtime, qkv, lens, B: int, S: int, heads: int) -> np.ndarray:
+    qkv = np.ascontiguousarray(qkv, np.float32)
+    lens = np.ascontiguousarray(lens, np.int32)
+    out = np.empty((B * S, heads * 64), np.float32)
+    _check(lib().sc_diag_attention(rt.handle, qkv.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S, heads,
+                                   out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def topk_merge_host(metric: str, dist: np.ndarray, rows: np.ndarray) -> tuple[np.ndarray, np.ndarray]:

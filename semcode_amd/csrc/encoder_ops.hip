@@ -1,0 +1,372 @@
+// encoder_ops.hip -- the non-GEMM kernels of the transformer-encoder forward (gfx950).
+//
+// Replaces (reference): what llama.cpp's BERT graph does around the matmuls behind
+// LlamaCppEmbeddings.embed_documents / embed_query (src/semcode/embeddings/providers.py:69-100;
+// call sites src/semcode/services/indexer.py:150, src/semcode/rag/pipeline.py:171-175):
+// token/position/type embedding + LayerNorm, post-attention / post-FFN LayerNorm, masked softmax
+// attention, masked mean pooling.  Arithmetic follows BertModel (post-LN, eps inside sqrt, biased
+// variance, erf-GELU, additive key mask), restated on CPU in oracle/bert_oracle.py.
+//
+//   embed_ln_kernel   HBM-bound  : 1 wave / token, f32 tables -> bf16 activations
+//   layernorm_kernel  HBM-bound  : 1 wave / token, bf16 -> bf16 (the residual add is fused into the
+//                                  producing GEMM's epilogue)
+//   attention_kernel  MFMA + LDS : 1 workgroup / (chunk, head); K and V of the head stay in LDS,
+//                                  S^T = K Q^T on v_mfma_f32_32x32x16_bf16 so a lane owns one query
+//                                  column, softmax in registers, P feeds P V straight from the
+//                                  accumulator registers, V fragments by ds_read_b64_tr_b16
+//   mean_pool_kernel  HBM-bound  : 1 workgroup / chunk, masked mean (+ optional L2 normalise) -> f32
+#include "sc_common.h"
+
+typedef unsigned short bf16_t;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+static __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+static __device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+#define LN_MAXJ 8  // hidden <= 2048
+
+// ------------------------------------------------------------------ embeddings + LayerNorm
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int tokens, int S, int H, int vocab, int max_pos,
+                                                        const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                        const float* __restrict__ temb, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= tokens) return;
+    int id = ids[tok];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pos = tok % S;
+    pos = pos >= max_pos ? max_pos - 1 : pos;
+    const float* we = wemb + (size_t)id * H;
+    const float* pe = pemb + (size_t)pos * H;
+    f32x4 v[LN_MAXJ];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+            v[j] = *reinterpret_cast<const f32x4*>(we + k0) + *reinterpret_cast<const f32x4*>(pe + k0) + *reinterpret_cast<const f32x4*>(temb + k0);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = v[j][c] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+    bf16_t* o = out + (size_t)tok * H;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k0);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k0);
+            u16x4 r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = f2bf((v[j][c] - mean) * rstd * g[c] + b[c]);
+            *reinterpret_cast<u16x4*>(o + k0) = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm (input already holds x + sublayer(x))
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ in, int tokens, int H, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= tokens) return;
+    const bf16_t* x = in + (size_t)tok * H;
+    f32x4 v[LN_MAXJ];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+            const u16x4 raw = *reinterpret_cast<const u16x4*>(x + k0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[j][c] = bf2f(raw[c]);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = v[j][c] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+    bf16_t* o = out + (size_t)tok * H;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int k0 = 4 * lane + 256 * j;
+        if (k0 < H) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k0);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k0);
+            u16x4 r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = f2bf((v[j][c] - mean) * rstd * g[c] + b[c]);
+            *reinterpret_cast<u16x4*>(o + k0) = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention (head dim 64)
+// qkv: [tokens, 3H] bf16 rows = [Q | K | V], head h at columns h*64 of each third.  ctx: [tokens, H].
+// KT = S / 32 key tiles.  LDS: K image [S][64] with chunk ^= (row>>1)&7, V image [S][64] with
+// chunk ^= ((row>>1)&1)<<2 (conflict-free for ds_read_b128 rows / ds_read_b64_tr_b16 blocks).
+template <int KT>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
+                                                         bf16_t* __restrict__ ctx) {
+    constexpr int S = KT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + S * 128;
+    float* invl = reinterpret_cast<float*>(smem + 2 * S * 128);  // [4 waves][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int ld = 3 * H;
+    const bf16_t* base = qkv + (size_t)b * S * ld + head * 64;
+    int len = lens[b];
+    len = len < 1 ? 1 : (len > S ? S : len);
+
+    // ---- stage K and V of this (chunk, head): S*128 B each = S/8 pieces of 1 KiB
+    for (int piece = w; piece < S / 8; piece += 4) {
+        const int p = piece * 64 + lane;
+        const int r = p >> 3, pos = p & 7;
+        const int ck = pos ^ ((r >> 1) & 7);
+        const int cv = pos ^ (((r >> 1) & 1) << 2);
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + H + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + 2 * H + cv * 8), (lds_vptr)(Vl + piece * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float sl2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    for (int qb = w; qb < KT; qb += 4) {
+        // Q fragments: B operand, lane (q = l31, hh) holds Q[q][16 ks + 8 hh .. +7]
+        const bf16_t* qrow = base + (size_t)(qb * 32 + l31) * ld;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks + 8 * hh);
+
+        // S^T tiles: st[t][r] = score(key = 32 t + (r&3) + 8 (r>>2) + 4 hh, query = l31)
+        f32x16 st[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int krow = 32 * t + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + hh;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+            }
+            st[t] = acc;
+        }
+        // masked softmax over keys (registers + the other half-wave)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key < len) mx = fmaxf(mx, st[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = mx * sl2;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float p = key < len ? exp2f(fmaf(st[t][r], sl2, -mb)) : 0.f;
+                st[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        invl[w * 32 + l31] = 1.0f / sum;
+
+        // O = P V: A operand = P straight from the score registers (k order of step s:
+        // key = 32 t + 16 s + 8 (j>>2) + 4 hh + (j&3)), B operand = V by transposed LDS reads
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(st[t][8 * s + j]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    bf16x8 vf;
+#pragma unroll
+                    for (int piece = 0; piece < 2; ++piece) {
+                        const int row = 32 * t + 16 * s + 8 * piece + 4 * hh + ((lane & 15) >> 2);
+                        const int d0 = 32 * dt + 16 * ((lane >> 4) & 1);
+                        const int chunk = (d0 >> 3) + ((lane & 3) >> 1);
+                        const int sw = chunk ^ (((row >> 1) & 1) << 2);
+                        typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
+                        const s16x4 got = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(Vl + row * 128 + sw * 16 + 8 * (lane & 1)));
+                        vf[4 * piece + 0] = got[0];
+                        vf[4 * piece + 1] = got[1];
+                        vf[4 * piece + 2] = got[2];
+                        vf[4 * piece + 3] = got[3];
+                    }
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o1, 0, 0, 0);
+                }
+            }
+        }
+        // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]; normalise by 1/l[q], store bf16
+        bf16_t* obase = ctx + (size_t)(b * S + qb * 32) * H + head * 64 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 il = *reinterpret_cast<const f32x4*>(invl + w * 32 + 8 * g + 4 * hh);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = 8 * g + 4 * hh + c;
+                obase[(size_t)q * H] = f2bf(o0[4 * g + c] * il[c]);
+                obase[(size_t)q * H + 32] = f2bf(o1[4 * g + c] * il[c]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ masked mean pooling
+__global__ __launch_bounds__(256) void mean_pool_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ lens, int S, int H,
+                                                         int normalize, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int len = lens[b];
+    len = len < 1 ? 1 : (len > S ? S : len);
+    const float inv = 1.0f / (float)len;
+    float ss = 0.f;
+    for (int k0 = 4 * tid; k0 < H; k0 += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* p = x + (size_t)b * S * H + k0;
+        for (int s = 0; s < len; ++s) {
+            const u16x4 raw = *reinterpret_cast<const u16x4*>(p + (size_t)s * H);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += bf2f(raw[c]);
+        }
+        acc *= inv;
+        *reinterpret_cast<f32x4*>(out + (size_t)b * H + k0) = acc;
+        ss += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+    }
+    if (normalize) {
+        red[tid] = ss;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const float scale = 1.0f / fmaxf(sqrtf(red[0]), 1e-12f);
+        for (int k0 = 4 * tid; k0 < H; k0 += 1024) {
+            f32x4 v = *reinterpret_cast<f32x4*>(out + (size_t)b * H + k0);
+            v *= scale;
+            *reinterpret_cast<f32x4*>(out + (size_t)b * H + k0) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ f32 -> bf16 weight conversion, fills
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+__global__ __launch_bounds__(256) void synth_scaled_kernel(float* __restrict__ out, int64_t n, uint64_t key, float scale, float offset) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = offset + scale * sc_synth_value(key, (uint64_t)i, 0u, 1u);
+}
+
+// ------------------------------------------------------------------ launchers
+void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab, int max_pos, const float* wemb, const float* pemb,
+                        const float* temb, const float* g, const float* b, float eps, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, s, ids, tokens, S, H, vocab, max_pos, wemb, pemb, temb,
+                       g, b, eps, (bf16_t*)out);
+}
+void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, s, (const bf16_t*)in, tokens, H, g, b, eps, (bf16_t*)out);
+}
+template <int KT>
+static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, void* ctx, hipStream_t s) {
+    const size_t lds = (size_t)KT * 32 * 256 + 512;
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL(attention_kernel<KT>, dim3((unsigned)(H / 64), (unsigned)B), dim3(256), lds, s, (const bf16_t*)qkv, lens, H, (bf16_t*)ctx);
+}
+bool sc_attention_supported(int S, int H, int heads) {
+    return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512);
+}
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, void* ctx, hipStream_t s) {
+    switch (S) {
+        case 32: launch_attn<1>(qkv, lens, B, H, ctx, s); break;
+        case 64: launch_attn<2>(qkv, lens, B, H, ctx, s); break;
+        case 128: launch_attn<4>(qkv, lens, B, H, ctx, s); break;
+        case 256: launch_attn<8>(qkv, lens, B, H, ctx, s); break;
+        case 512: launch_attn<16>(qkv, lens, B, H, ctx, s); break;
+        default: break;
+    }
+}
+void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x, lens, S, H, normalize, out);
+}
+void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, (bf16_t*)out, n);
+}
+void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)in, out, n);
+}
+void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, float offset, hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(synth_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, sc_synth_key(seed), scale, offset);
+}

@@ -1,0 +1,375 @@
+// sc_encoder.cpp -- host side of the transformer-encoder entry points (include/semcode_hip.h).
+//
+// Mirrors (reference): the object EmbeddingProviderFactory.create() returns and its
+// embed_documents / embed_query (src/semcode/embeddings/providers.py:34-104; third-party forward in
+// llama.cpp): token ids in, one pooled vector per chunk out.  Tokenisation stays on the host side of
+// the boundary (semcode_amd/embeddings/tokenizer.py).
+//
+// Forward per layer (BERT, post-LN):  QKV = X Wqkv^T + b  ->  attention  ->  Y = ctx Wo^T + bo + X
+//   -> X1 = LN(Y) -> Hm = gelu(X1 W1^T + b1) -> Y2 = Hm W2^T + b2 + X1 -> X = LN(Y2); pooled = masked mean.
+// Activations bf16 in HBM ([tokens, H] row-major, tokens padded to 128), weights bf16 [out, in],
+// biases / LayerNorm parameters / embedding tables f32.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "sc_internal.h"
+
+// gemm_bf16.hip / encoder_ops.hip
+bool sc_gemm_bf16_supported(int M, int N, int K);
+void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
+                         int ldc, int M, int N, int K, hipStream_t s);
+void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab, int max_pos, const float* wemb, const float* pemb,
+                        const float* temb, const float* g, const float* b, float eps, void* out, hipStream_t s);
+void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s);
+bool sc_attention_supported(int S, int H, int heads);
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, void* ctx, hipStream_t s);
+void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s);
+void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, float offset, hipStream_t s);
+void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s);
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
+
+struct LayerW {
+    void* wqkv;  // bf16 [3H, H]
+    float* bqkv; // [3H]
+    void* wo;    // bf16 [H, H]
+    float* bo;
+    float *ln1g, *ln1b;
+    void* w1;    // bf16 [F, H]
+    float* b1;
+    void* w2;    // bf16 [H, F]
+    float* b2;
+    float *ln2g, *ln2b;
+};
+
+struct sc_encoder {
+    sc_runtime* rt = nullptr;
+    sc_encoder_cfg cfg{};
+    char* params = nullptr;  // one device allocation holding every parameter
+    size_t params_bytes = 0;
+    float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *embg = nullptr, *embb = nullptr;
+    std::vector<LayerW> layers;
+    // workspace for `ws_tokens` (multiple of 128) tokens
+    int64_t ws_tokens = 0;
+    char* ws = nullptr;
+    void *x = nullptr, *x1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hm = nullptr;
+    int32_t* ids = nullptr;
+    int32_t* lens = nullptr;
+    float* pooled = nullptr;
+    int64_t ws_batch = 0;
+    std::mutex mu;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// number of f32 values in the weight blob, in blob order (see include/semcode_hip.h)
+static int64_t blob_floats(const sc_encoder_cfg& c) {
+    const int64_t H = c.hidden, F = c.ffn;
+    int64_t n = (int64_t)c.vocab * H + (int64_t)c.max_pos * H + (int64_t)c.type_vocab * H + 2 * H;
+    n += (int64_t)c.layers * (4 * (H * H + H) + 2 * H + (F * H + F) + (H * F + H) + 2 * H);
+    return n;
+}
+
+extern "C" sc_status sc_encoder_blob_bytes(const sc_encoder_cfg* cfg, int64_t* out) {
+    if (!cfg || !out) return sc_fail(SC_ERR_INVALID, "sc_encoder_blob_bytes: NULL argument");
+    *out = blob_floats(*cfg) * 4;
+    return SC_OK;
+}
+
+static sc_status check_cfg(const sc_encoder_cfg& c) {
+    if (c.vocab < 1 || c.hidden < 1 || c.layers < 1 || c.heads < 1 || c.ffn < 1 || c.max_pos < 1 || c.type_vocab < 1)
+        return sc_fail(SC_ERR_INVALID, "sc_encoder_create: non-positive model dimension");
+    if (c.hidden != c.heads * 64) return sc_fail(SC_ERR_UNSUPPORTED, "sc_encoder_create: head dimension must be 64 (hidden=%d heads=%d)", c.hidden, c.heads);
+    if (c.hidden % 128 || c.ffn % 128 || c.hidden > 2048)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_encoder_create: hidden (<=2048) and ffn must be multiples of 128 (got %d, %d)", c.hidden, c.ffn);
+    if (!(c.ln_eps > 0.f)) return sc_fail(SC_ERR_INVALID, "sc_encoder_create: ln_eps must be > 0");
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg, const void* weights_blob, size_t nbytes, sc_encoder** out) {
+    if (!rt || !cfg || !out) return sc_fail(SC_ERR_INVALID, "sc_encoder_create: NULL argument");
+    *out = nullptr;
+    sc_status st = check_cfg(*cfg);
+    if (st) return st;
+    const int64_t nfl = blob_floats(*cfg);
+    if (weights_blob && (int64_t)nbytes != nfl * 4)
+        return sc_fail(SC_ERR_INVALID, "sc_encoder_create: weight blob is %zu bytes, config needs %lld", nbytes, (long long)(nfl * 4));
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    sc_encoder* e = new (std::nothrow) sc_encoder();
+    if (!e) return sc_fail(SC_ERR_NOMEM, "out of host memory");
+    e->rt = rt;
+    e->cfg = *cfg;
+    const int64_t H = cfg->hidden, F = cfg->ffn, L = cfg->layers;
+
+    // staging copy of the f32 blob on device (freed after conversion)
+    float* blob = nullptr;
+    hipError_t he = hipMalloc((void**)&blob, (size_t)nfl * 4);
+    if (he != hipSuccess) {
+        delete e;
+        return sc_fail(SC_ERR_NOMEM, "hipMalloc weight staging (%lld B) failed: %s", (long long)nfl * 4, hipGetErrorString(he));
+    }
+    auto fail = [&](sc_status code) {
+        hipFree(blob);
+        hipFree(e->params);
+        delete e;
+        return code;
+    };
+    // parameter arena: f32 tables + per-layer {bf16 matrices, f32 vectors}
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { size_t o = total; total += align256(bytes); return o; };
+    const size_t o_wemb = reserve((size_t)cfg->vocab * H * 4), o_pemb = reserve((size_t)cfg->max_pos * H * 4),
+                 o_temb = reserve((size_t)cfg->type_vocab * H * 4), o_eg = reserve(H * 4), o_eb = reserve(H * 4);
+    struct LO { size_t wqkv, bqkv, wo, bo, l1g, l1b, w1, b1, w2, b2, l2g, l2b; };
+    std::vector<LO> lo(L);
+    for (int64_t l = 0; l < L; ++l) {
+        lo[l].wqkv = reserve(3 * H * H * 2); lo[l].bqkv = reserve(3 * H * 4); lo[l].wo = reserve(H * H * 2); lo[l].bo = reserve(H * 4);
+        lo[l].l1g = reserve(H * 4); lo[l].l1b = reserve(H * 4); lo[l].w1 = reserve(F * H * 2); lo[l].b1 = reserve(F * 4);
+        lo[l].w2 = reserve(H * F * 2); lo[l].b2 = reserve(H * 4); lo[l].l2g = reserve(H * 4); lo[l].l2b = reserve(H * 4);
+    }
+    he = hipMalloc((void**)&e->params, total);
+    if (he != hipSuccess) return fail(sc_fail(SC_ERR_NOMEM, "hipMalloc parameters (%zu B) failed: %s", total, hipGetErrorString(he)));
+    e->params_bytes = total;
+
+    if (weights_blob) {
+        he = hipMemcpyAsync(blob, weights_blob, (size_t)nfl * 4, hipMemcpyHostToDevice, s);
+        if (he != hipSuccess) return fail(sc_fail(SC_ERR_HIP, "weight upload failed: %s", hipGetErrorString(he)));
+    } else {
+        // synthetic weights: every tensor ~ 0.02 * N(0,1) over the blob index, then LayerNorm gamma = 1,
+        // beta = 0 and biases = 0 are overwritten below (same rule in oracle/bert_oracle.py synth_weights)
+        sc_launch_synth_scaled(blob, nfl, cfg->synth_seed, 0.02f, 0.0f, s);
+    }
+    // walk the blob in its documented order
+    int64_t off = 0;
+    auto take = [&](int64_t n) { float* p = blob + off; off += n; return p; };
+    auto put_f32 = [&](size_t dst, const float* src, int64_t n, int fill /*0 copy, 1 ones, 2 zeros*/) {
+        float* d = (float*)(e->params + dst);
+        if (!weights_blob && fill == 1) sc_launch_synth_scaled(d, n, 0, 0.0f, 1.0f, s);
+        else if (!weights_blob && fill == 2) hipMemsetAsync(d, 0, (size_t)n * 4, s);
+        else hipMemcpyAsync(d, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        return d;
+    };
+    auto put_bf16 = [&](size_t dst, const float* src, int64_t n) {
+        void* d = e->params + dst;
+        sc_launch_f32_to_bf16(src, d, n, s);
+        return d;
+    };
+    e->wemb = put_f32(o_wemb, take((int64_t)cfg->vocab * H), (int64_t)cfg->vocab * H, 0);
+    e->pemb = put_f32(o_pemb, take((int64_t)cfg->max_pos * H), (int64_t)cfg->max_pos * H, 0);
+    e->temb = put_f32(o_temb, take((int64_t)cfg->type_vocab * H), (int64_t)cfg->type_vocab * H, 0);
+    e->embg = put_f32(o_eg, take(H), H, 1);
+    e->embb = put_f32(o_eb, take(H), H, 2);
+    e->layers.resize(L);
+    for (int64_t l = 0; l < L; ++l) {
+        LayerW& w = e->layers[l];
+        // blob order: Wq bq Wk bk Wv bv Wo bo ln1g ln1b W1 b1 W2 b2 ln2g ln2b ; device: Wqkv = [Wq; Wk; Wv]
+        char* wqkv = e->params + lo[l].wqkv;
+        float* bqkv = (float*)(e->params + lo[l].bqkv);
+        for (int p = 0; p < 3; ++p) {
+            const float* wp = take(H * H);
+            sc_launch_f32_to_bf16(wp, wqkv + (size_t)p * H * H * 2, H * H, s);
+            const float* bp = take(H);
+            if (weights_blob) hipMemcpyAsync(bqkv + p * H, bp, H * 4, hipMemcpyDeviceToDevice, s);
+            else hipMemsetAsync(bqkv + p * H, 0, H * 4, s);
+        }
+        w.wqkv = wqkv;
+        w.bqkv = bqkv;
+        w.wo = put_bf16(lo[l].wo, take(H * H), H * H);
+        w.bo = put_f32(lo[l].bo, take(H), H, 2);
+        w.ln1g = put_f32(lo[l].l1g, take(H), H, 1);
+        w.ln1b = put_f32(lo[l].l1b, take(H), H, 2);
+        w.w1 = put_bf16(lo[l].w1, take(F * H), F * H);
+        w.b1 = put_f32(lo[l].b1, take(F), F, 2);
+        w.w2 = put_bf16(lo[l].w2, take(H * F), H * F);
+        w.b2 = put_f32(lo[l].b2, take(H), H, 2);
+        w.ln2g = put_f32(lo[l].l2g, take(H), H, 1);
+        w.ln2b = put_f32(lo[l].l2b, take(H), H, 2);
+    }
+    he = hipStreamSynchronize(s);
+    if (he == hipSuccess) he = hipGetLastError();
+    if (he != hipSuccess) return fail(sc_fail(SC_ERR_HIP, "encoder parameter setup failed: %s", hipGetErrorString(he)));
+    hipFree(blob);
+    *out = e;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_destroy(sc_encoder* e) {
+    if (!e) return SC_OK;
+    hipSetDevice(e->rt->device);
+    hipStreamSynchronize(e->rt->stream);
+    hipFree(e->params);
+    hipFree(e->ws);
+    delete e;
+    return SC_OK;
+}
+
+static sc_status ensure_ws(sc_encoder* e, int64_t B, int64_t S) {
+    const int64_t tokens = (B * S + 127) / 128 * 128;
+    if (tokens <= e->ws_tokens && B <= e->ws_batch) return SC_OK;
+    SC_HIP(hipStreamSynchronize(e->rt->stream));
+    hipFree(e->ws);
+    e->ws = nullptr;
+    e->ws_tokens = 0;
+    e->ws_batch = 0;
+    const int64_t H = e->cfg.hidden, F = e->cfg.ffn;
+    const int64_t nb = B > e->ws_batch ? B : e->ws_batch;
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { size_t o = total; total += align256(bytes); return o; };
+    const size_t ox = reserve(tokens * H * 2), ox1 = reserve(tokens * H * 2), oy = reserve(tokens * H * 2), oqkv = reserve(tokens * 3 * H * 2),
+                 octx = reserve(tokens * H * 2), ohm = reserve(tokens * F * 2), oids = reserve(tokens * 4), olens = reserve(nb * 4),
+                 opool = reserve(nb * H * 4);
+    hipError_t he = hipMalloc((void**)&e->ws, total);
+    if (he != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc encoder workspace (%zu B) failed: %s", total, hipGetErrorString(he));
+    SC_HIP(hipMemsetAsync(e->ws, 0, total, e->rt->stream));  // padded rows must hold finite values
+    e->x = e->ws + ox; e->x1 = e->ws + ox1; e->y = e->ws + oy; e->qkv = e->ws + oqkv; e->ctx = e->ws + octx; e->hm = e->ws + ohm;
+    e->ids = (int32_t*)(e->ws + oids); e->lens = (int32_t*)(e->ws + olens); e->pooled = (float*)(e->ws + opool);
+    e->ws_tokens = tokens;
+    e->ws_batch = nb;
+    return SC_OK;
+}
+
+// ids_dev [B,S], lens_dev [B] device pointers; out_dev [B,H] f32 device.  Caller holds e->mu.
+static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S, float* out_dev) {
+    const sc_encoder_cfg& c = e->cfg;
+    sc_runtime* rt = e->rt;
+    hipStream_t s = rt->stream;
+    const int H = c.hidden, F = c.ffn;
+    const int tokens = B * S;
+    const int M = (tokens + 127) / 128 * 128;
+    sc_launch_embed_ln(ids_dev, tokens, S, H, c.vocab, c.max_pos, e->wemb, e->pemb, e->temb, e->embg, e->embb, c.ln_eps, e->x, s);
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerW& w = e->layers[l];
+        hipEvent_t g0, g1;
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16(EPI_BIAS, e->x, H, w.wqkv, H, w.bqkv, nullptr, 0, e->qkv, 3 * H, M, 3 * H, H, s);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        hipEvent_t a0, a1;
+        sc_prof_begin(rt, SC_PROF_ATTN, &a0, &a1);
+        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->ctx, s);
+        sc_prof_end(rt, SC_PROF_ATTN, a0, a1);
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, e->ctx, H, w.wo, H, w.bo, e->x, H, e->y, H, M, H, H, s);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        sc_launch_layernorm(e->y, tokens, H, w.ln1g, w.ln1b, c.ln_eps, e->x1, s);
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, e->hm, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        sc_launch_layernorm(e->y, tokens, H, w.ln2g, w.ln2b, c.ln_eps, e->x, s);
+    }
+    sc_launch_mean_pool(e->x, lens_dev, B, S, H, c.normalize, out_dev, s);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
+
+static sc_status check_embed_args(sc_encoder* e, const void* ids, const void* lens, int32_t B, int32_t S, const void* out) {
+    if (!e || !ids || !lens || !out) return sc_fail(SC_ERR_INVALID, "embed: NULL argument");
+    if (B < 1 || B > 65536) return sc_fail(SC_ERR_INVALID, "embed: batch %d out of range", B);
+    if (!sc_attention_supported(S, e->cfg.hidden, e->cfg.heads))
+        return sc_fail(SC_ERR_UNSUPPORTED, "embed: sequence length %d not in {32,64,128,256,512} (pad on the host)", S);
+    if (S > e->cfg.max_pos) return sc_fail(SC_ERR_INVALID, "embed: sequence length %d exceeds max_pos %d", S, e->cfg.max_pos);
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_embed_ids_dev(sc_encoder* e, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S,
+                                              float* out_dev) {
+    sc_status st = check_embed_args(e, ids_dev, lens_dev, B, S, out_dev);
+    if (st) return st;
+    std::lock_guard<std::mutex> g(e->mu);
+    SC_HIP(hipSetDevice(e->rt->device));
+    st = ensure_ws(e, B, S);
+    if (st) return st;
+    return forward_locked(e, ids_dev, lens_dev, B, S, out_dev);
+}
+
+extern "C" sc_status sc_encoder_embed_ids(sc_encoder* e, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, float* out) {
+    sc_status st = check_embed_args(e, ids, lens, B, S, out);
+    if (st) return st;
+    std::lock_guard<std::mutex> g(e->mu);
+    SC_HIP(hipSetDevice(e->rt->device));
+    st = ensure_ws(e, B, S);
+    if (st) return st;
+    hipStream_t s = e->rt->stream;
+    SC_HIP(hipMemcpyAsync(e->ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(e->lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    st = forward_locked(e, e->ids, e->lens, B, S, e->pooled);
+    if (st) return st;
+    SC_HIP(hipMemcpyAsync(out, e->pooled, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_info(sc_encoder* e, sc_encoder_cfg* cfg_out) {
+    if (!e || !cfg_out) return sc_fail(SC_ERR_INVALID, "sc_encoder_info: NULL argument");
+    *cfg_out = e->cfg;
+    return SC_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics (single-kernel parity tests)
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+// host f32 [n] -> device bf16 (through a device f32 staging buffer)
+sc_status upload_bf16(const float* host, int64_t n, DevBuf& f32buf, DevBuf& out, hipStream_t s) {
+    if (f32buf.alloc((size_t)n * 4) != hipSuccess || out.alloc((size_t)n * 2) != hipSuccess) return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    SC_HIP(hipMemcpyAsync(f32buf.p, host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    sc_launch_f32_to_bf16((const float*)f32buf.p, out.p, n, s);
+    return SC_OK;
+}
+}  // namespace
+
+extern "C" sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const float* W, const float* bias, const float* R,
+                                       int32_t M, int32_t N, int32_t K, float* out) {
+    if (!rt || !A || !W || !bias || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bf16: NULL argument");
+    if (epi < 0 || epi > 2 || (epi == EPI_BIAS_RES && !R)) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bf16: bad epilogue / missing residual");
+    if (!sc_gemm_bf16_supported(M, N, K)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_bf16: need M%%128==0, N%%128==0, K%%64==0");
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    DevBuf fa, fw, fr, da, dw, dr, db, dc, fo;
+    sc_status st = upload_bf16(A, (int64_t)M * K, fa, da, s);
+    if (st) return st;
+    st = upload_bf16(W, (int64_t)N * K, fw, dw, s);
+    if (st) return st;
+    if (R) {
+        st = upload_bf16(R, (int64_t)M * N, fr, dr, s);
+        if (st) return st;
+    }
+    if (db.alloc((size_t)N * 4) != hipSuccess || dc.alloc((size_t)M * N * 2) != hipSuccess || fo.alloc((size_t)M * N * 4) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    SC_HIP(hipMemcpyAsync(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    sc_launch_bf16_to_f32(dc.p, (float*)fo.p, (int64_t)M * N, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(out, fo.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out) {
+    if (!rt || !qkv || !lens || !out || B < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_attention: bad argument");
+    const int H = heads * 64;
+    if (!sc_attention_supported(S, H, heads)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_attention: S must be one of 32,64,128,256,512");
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    const int64_t tokens = (int64_t)B * S;
+    DevBuf fq, dq, dl, dc, fo;
+    sc_status st = upload_bf16(qkv, tokens * 3 * H, fq, dq, s);
+    if (st) return st;
+    if (dl.alloc((size_t)B * 4) != hipSuccess || dc.alloc((size_t)tokens * H * 2) != hipSuccess || fo.alloc((size_t)tokens * H * 4) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    SC_HIP(hipMemcpyAsync(dl.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    sc_launch_attention(dq.p, (const int32_t*)dl.p, B, S, H, dc.p, s);
+    sc_launch_bf16_to_f32(dc.p, (float*)fo.p, tokens * H, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(out, fo.p, (size_t)tokens * H * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
