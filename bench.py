@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on MI355X: top-k QPS over 10M x 768 (and chunks/s embed, when built).
+"""bench.py -- BASELINE.json's metric on MI355X: chunks/s embed (256-token chunks) + top-k QPS over 10M x 768.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A "step" is one pass of the hot path over one batch of synthetic input that is
-already resident in HBM: one top-k search of a query batch over this rank's corpus shard
-(row-range sharding, weak scaling: `--rows` rows PER GPU), followed for N > 1 by the RCCL all-gather of
-the per-shard [Q, k] results and the host-side final merge on rank 0.
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Two workloads, both with
+inputs already resident in HBM when the timed region starts:
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).  The CPU oracle is used here only
-for the `cpu_baseline` leg (timed on a bounded sample, rank 0, N = 1) -- never on the measured path.
+  embed (BASELINE configs[1], the primary `value`): one step = the transformer-encoder forward over a
+      batch of 256 chunks x 256 token ids (BERT-base shape, bf16 MFMA, random-init weights), pooled
+      f32 vectors out.  Pure data parallel: every rank embeds its own batch, no collective;
+      value = chunks of all ranks / max-over-ranks time.
+  scan (BASELINE configs[2]/[3], reported under "topk"): one step = brute-force L2 top-10 of a
+      batch of 1024 queries over this rank's 10M x 768 f32 shard (row-range sharding, weak scaling),
+      then for N > 1 the RCCL all-gather of the per-shard [Q, k] results and the host-side merge on rank 0.
+
+Rank 0 prints ONE JSON line.  The CPU oracle is used only for the `cpu_baseline` legs (bounded samples,
+rank 0, N = 1) -- never on the measured path.
 """
 from __future__ import annotations
 
@@ -24,27 +30,199 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="both", choices=["both", "embed", "scan"])
+    # embed
+    ap.add_argument("--batch", type=int, default=256, help="chunks per step per GPU")
+    ap.add_argument("--seq", type=int, default=256, help="tokens per chunk")
+    # scan
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per GPU")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric-type", default="L2", choices=["L2", "IP", "COSINE"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="also time Q in {1,16,256} (extra keys, same JSON line)")
+    ap.add_argument("--sweep", action="store_true", help="scan: also time Q in {1,16,256}")
     return ap.parse_args()
 
 
-def cpu_baseline(args) -> dict:
-    """The oracle (a scalar-chain C port, OpenMP over queries/rows) on a bounded sample of the workload."""
+class Ctx:
+    pass
+
+
+def timed(ctx, fn, nsteps):
+    """EXACTLY nsteps calls of fn, bracketed by barrier + synchronize on both sides; max over ranks."""
+    import torch
+
+    torch.cuda.synchronize()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        fn()
+    torch.cuda.synchronize()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ctx.world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.dev)
+        ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ------------------------------------------------------------------------------------------ embed
+
+def encoder_flops_per_chunk(S: int, H: int = 768, L: int = 12, F: int = 3072):
+    gemm = L * 2 * S * H * (3 * H + H + 2 * F)   # QKV + out-proj + FFN1 + FFN2
+    attn = L * 4 * S * S * H                     # QK^T + PV
+    return gemm, attn                            # S=256: 4.349e10 + 2.416e9 = 4.590e10 (SURVEY section 8d)
+
+
+def bench_embed(ctx, args) -> dict:
+    import torch
+
+    from semcode_amd import _native
+
+    B, S = args.batch, args.seq
+    enc = _native.Encoder(ctx.rt, dict(_native.BERT_BASE), weights=None, synth_seed=0)
+    g = torch.Generator(device="cpu").manual_seed(1 + ctx.rank)
+    ids = torch.randint(1000, 30000, (B, S), generator=g, dtype=torch.int32).to(ctx.dev)
+    lens = torch.full((B,), S, dtype=torch.int32, device=ctx.dev)
+    out = torch.empty((B, 768), dtype=torch.float32, device=ctx.dev)
+
+    def step():
+        enc.embed_ids_dev(ids.data_ptr(), lens.data_ptr(), B, S, out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    ctx.rt.set_profiling(True)
+    ctx.rt.profile_reset()
+    dt = timed(ctx, step, args.steps)
+    gemm_ms, gemm_n = ctx.rt.profile_read(2)
+    attn_ms, attn_n = ctx.rt.profile_read(3)
+    ctx.rt.set_profiling(False)
+    assert bool(torch.isfinite(out).all()), "encoder produced non-finite values"
+    enc.close()
+
+    gemm_fl, attn_fl = encoder_flops_per_chunk(S)
+    chunks_s = B * ctx.world * args.steps / dt
+    gemm_tflops = (gemm_fl * B * args.steps) / (gemm_ms * 1e-3) / 1e12 if gemm_n else None
+    res = {
+        "chunks_per_s": chunks_s,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "workload": f"encoder forward, {B} chunks x {S} tokens per GPU per step, BERT-base shape (12x768, 12 heads, FFN 3072), bf16 MFMA / f32 accumulate, random-init weights",
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS if gemm_tflops else None, "traffic": None,
+                     "algorithmic_flops_per_launch": gemm_fl * B / 48, "avg_launch_ms": gemm_ms / max(1, gemm_n), "launches": gemm_n,
+                     "attention_avg_launch_ms": attn_ms / max(1, attn_n),
+                     "end_to_end_tflops": chunks_s / ctx.world * (gemm_fl + attn_fl) / 1e12,
+                     "end_to_end_frac": chunks_s / ctx.world * (gemm_fl + attn_fl) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+    }
+    return res
+
+
+def cpu_baseline_embed(args) -> dict:
+    """numpy f32 restatement (BLAS threads = host cores) on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import bert_oracle as bo
+
+    cfg = dict(bo.BERT_BASE)
+    blob = bo.make_blob(cfg, 0, "bench")
+    n = 16
+    rng = np.random.default_rng(1)
+    ids = rng.integers(1000, 30000, size=(n, args.seq)).astype(np.int32)
+    lens = np.full(n, args.seq, np.int32)
+    bo.forward(cfg, blob, ids[:2], lens[:2], dtype=np.float32)
+    t0 = time.perf_counter()
+    bo.forward(cfg, blob, ids, lens, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"value": n / dt, "unit": "chunks/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of {args.batch} chunks x {args.seq} tokens, numpy f32 restatement (BLAS on all cores), {dt:.2f}s"}
+
+
+# ------------------------------------------------------------------------------------------- scan
+
+def bench_scan(ctx, args) -> dict:
+    import torch
+
+    from semcode_amd import _native
+
+    Q, k, dim, rows = args.queries, args.k, args.dim, args.rows
+    rt, dev, world, rank = ctx.rt, ctx.dev, ctx.world, ctx.rank
+    ix = _native.Index(rt, dim, metric=args.metric_type, kind="FLAT", row_base=rank * rows)
+    ix.fill_synthetic(rows, seed=0, first_row=rank * rows)  # shard r = rows [r*rows, (r+1)*rows) of ONE global corpus
+    q = torch.empty((Q, dim), dtype=torch.float32, device=dev)
+    rt.synth_fill_dev(q.data_ptr(), Q, dim, dim, seed=1)
+    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    out_r = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    if world > 1:
+        all_d = torch.empty((world, Q, k), dtype=torch.float32, device=dev)
+        all_r = torch.empty((world, Q, k), dtype=torch.int64, device=dev)
+    rt.synchronize()
+
+    def step(nq=Q):
+        ix.search_dev(q.data_ptr(), nq, k, out_d.data_ptr(), out_r.data_ptr())
+        if world > 1:  # the one exchange step of the path: per-shard [Q,k] -> every rank, then host merge
+            ctx.dist.all_gather_into_tensor(all_d, out_d)
+            ctx.dist.all_gather_into_tensor(all_r, out_r)
+            if rank == 0:
+                _native.topk_merge_host(args.metric_type, all_d.cpu().numpy(), all_r.cpu().numpy())
+
+    for _ in range(args.warmup):
+        step()
+    rt.set_profiling(True)
+    rt.profile_reset()
+    dt = timed(ctx, step, args.steps)
+    scan_ms, scan_n = rt.profile_read(0)
+    merge_ms, merge_n = rt.profile_read(1)
+    rt.set_profiling(False)
+
+    sweep = None
+    if args.sweep:
+        sweep = []
+        for nq in (1, 16, 256):
+            for _ in range(2):
+                step(nq)
+            t = timed(ctx, lambda: step(nq), args.steps)
+            sweep.append({"queries": nq, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps / t,
+                          "corpus_gbs_per_gpu": rows * dim * 4 / (t / args.steps) / 1e9})
+    ix.close()
+
+    alg_bytes = rows * dim * 4  # SURVEY section 8d: the shard is read once per query batch (+ norms, negligible)
+    kern_ms = scan_ms / max(1, scan_n)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if scan_n else None
+    res = {
+        "value": Q * args.steps / dt,
+        "unit": "queries/s",
+        "ms_per_step": 1e3 * dt / args.steps,
+        "rows_scanned_per_s": Q * args.steps / dt * rows * world,
+        "workload": f"brute-force {args.metric_type} top-{k}, {rows} x {dim} f32 rows per GPU ({rows * world} total), batch-{Q} queries",
+        "dtype": "f32",
+        "roofline": {"bound": "hbm", "kernel": "scan_exact_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches": scan_n,
+                     "merge_avg_ms": merge_ms / max(1, merge_n)},
+    }
+    if sweep:
+        res["sweep"] = sweep
+    return res
+
+
+def cpu_baseline_scan(args) -> dict:
+    """The oracle (scalar fmaf-chain C port, OpenMP) on a bounded sample: 200k of the rows, all queries."""
     from oracle import sc_oracle as orc
 
     rows, nq = 200_000, args.queries
@@ -59,126 +237,69 @@ def cpu_baseline(args) -> dict:
             "sample": f"{rows} of {args.rows} rows x all {nq} queries in {dt:.2f}s, scaled linearly in rows"}
 
 
+# ------------------------------------------------------------------------------------------- main
+
 def main() -> None:
     args = parse()
-    import numpy as np
     import torch
 
     from semcode_amd import _native
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dist = None
+    if ctx.world == 1 and args.gpus > 1:
+        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
     torch.cuda.set_device(local)
-    if world > 1:
+    ctx.dev = torch.device("cuda", local)
+    ctx.dist = None
+    if ctx.world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    stream = torch.cuda.Stream(device=dev)
-    rt = _native.Runtime(device=local, stream=stream.cuda_stream)
-    info = rt.device_info()
+        dist.init_process_group("nccl", device_id=ctx.dev)  # RCCL over xGMI
+        ctx.dist = dist
+    stream = torch.cuda.Stream(device=ctx.dev)
+    ctx.rt = _native.Runtime(device=local, stream=stream.cuda_stream)
+    info = ctx.rt.device_info()
 
-    Q, k, dim, rows = args.queries, args.k, args.dim, args.rows
+    embed = scan = None
     with torch.cuda.stream(stream):
-        ix = _native.Index(rt, dim, metric=args.metric_type, kind="FLAT", row_base=rank * rows)
-        ix.fill_synthetic(rows, seed=0, first_row=rank * rows)  # shard r = rows [r*rows, (r+1)*rows) of one global corpus
-        q = torch.empty((Q, dim), dtype=torch.float32, device=dev)
-        rt.synth_fill_dev(q.data_ptr(), Q, dim, dim, seed=1)
-        out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
-        out_r = torch.empty((Q, k), dtype=torch.int64, device=dev)
-        if world > 1:
-            all_d = torch.empty((world, Q, k), dtype=torch.float32, device=dev)
-            all_r = torch.empty((world, Q, k), dtype=torch.int64, device=dev)
-        rt.synchronize()
+        if args.workload in ("both", "embed"):
+            embed = bench_embed(ctx, args)
+        if args.workload in ("both", "scan"):
+            scan = bench_scan(ctx, args)
 
-        def step(nq=Q):
-            ix.search_dev(q.data_ptr(), nq, k, out_d.data_ptr(), out_r.data_ptr())
-            if world > 1:
-                dist.all_gather_into_tensor(all_d, out_d)
-                dist.all_gather_into_tensor(all_r, out_r)
-                if rank == 0:
-                    return _native.topk_merge_host(args.metric_type, all_d.cpu().numpy(), all_r.cpu().numpy())
-            return None
-
-        def timed(nsteps, nq=Q):
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(nsteps):
-                step(nq)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            return dt
-
-        for _ in range(args.warmup):
-            step()
-        rt.set_profiling(True)
-        rt.profile_reset()
-        dt = timed(args.steps)
-        scan_ms, scan_n = rt.profile_read(0)
-        merge_ms, merge_n = rt.profile_read(1)
-        rt.set_profiling(False)
-
-        sweep = None
-        if args.sweep:
-            sweep = []
-            for nq in (1, 16, 256):
-                for _ in range(2):
-                    step(nq)
-                t = timed(args.steps, nq)
-                sweep.append({"queries": nq, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps / t,
-                              "corpus_gbs": rows * dim * 4 / (t / args.steps) / 1e9})
-
-    ms_per_step = 1e3 * dt / args.steps
-    qps = Q * args.steps / dt
-    alg_bytes = rows * dim * 4  # the corpus is read once per query batch (+ norms, negligible)
-    kern_ms = scan_ms / max(1, scan_n)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if scan_n else None
     line = {
-        "metric": "top-k QPS over 10M x 768 (chunks/sec embed: encoder not built yet this round)",
-        "value": qps,
-        "unit": "queries/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"brute-force {args.metric_type} top-{k}, {rows} x {dim} f32 rows per GPU, batch-{Q} queries",
-                   "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "queries": Q, "k": k,
-                   "metric_type": args.metric_type, "sharding": f"row-range x{world}", "device": info["name"]},
-        "roofline": {"bound": "hbm", "kernel": "scan_exact_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms, "launches": scan_n,
-                     "merge_avg_ms": merge_ms / max(1, merge_n)},
+        "metric": "chunks/sec embed (256-tok) + top-k QPS over 10M x 768",
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "data": "synthetic",
     }
-    if sweep:
-        line["sweep"] = sweep
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+    if embed:
+        line.update({"value": embed["chunks_per_s"], "unit": "chunks/s", "ms_per_step": embed["ms_per_step"], "dtype": "bf16",
+                     "config": {"workload": embed["workload"], "global_batch": args.batch * ctx.world, "seq_len": args.seq,
+                                "parallelism": f"dp{ctx.world} (replicated weights, no collective)", "device": info["name"]},
+                     "roofline": embed["roofline"]})
+        if scan:
+            line["topk"] = scan
+    else:
+        line.update({"value": scan["value"], "unit": "queries/s", "ms_per_step": scan["ms_per_step"], "dtype": "f32",
+                     "config": {"workload": scan["workload"], "sharding": f"row-range x{ctx.world}", "device": info["name"]},
+                     "roofline": scan["roofline"]})
+        if "sweep" in scan:
+            line["sweep"] = scan["sweep"]
+    if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            if embed:
+                line["cpu_baseline"] = cpu_baseline_embed(args)
+                if scan:
+                    line["topk"]["cpu_baseline"] = cpu_baseline_scan(args)
+            else:
+                line["cpu_baseline"] = cpu_baseline_scan(args)
         print(json.dumps(line), flush=True)
-    ix.close()
-    rt.close()
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.rt.close()
+    if ctx.world > 1:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
