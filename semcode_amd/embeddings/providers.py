@@ -1,0 +1,174 @@
+"""Embedding provider factory with the MI355X encoder as a provider.
+
+Reference: src/semcode/embeddings/providers.py:21-104.  `EmbeddingPayload` and
+`EmbeddingProviderFactory.create(provider=None, model=None)` keep their names, signature, dispatch on the
+lower-cased provider name and error types (NotImplementedError for unknown providers, ValueError when
+the llama.cpp model path is unset, RuntimeError when llama-cpp-python is missing), so
+IndexerService._embedding_client_instance (src/semcode/services/indexer.py:180-183) and
+SemanticSearchPipeline._embedding_client (src/semcode/rag/pipeline.py:298-301) work unchanged.  New
+provider names "mi355x" / "hip" select the HIP encoder (settings.embedding_provider = "mi355x").
+
+The returned object has LangChain's Embeddings surface -- embed_documents(list[str]) -> list[list[float]],
+embed_query(str) -> list[float] (duck-typed in reference tests/integration/test_indexer_service.py:7-12)
+-- plus array fast paths that skip the list-of-float boxing.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from ..settings import resolve as _resolve_settings
+from .payload import EmbeddingPayload
+from .tokenizer import HashTokenizer, WordPieceTokenizer, pack
+
+log = logging.getLogger(__name__)
+
+__all__ = ["EmbeddingPayload", "EmbeddingProviderFactory", "MI355XEmbeddings"]
+
+MI355X_PROVIDER_NAMES = {"mi355x", "hip", "rocm"}
+
+# HF BertModel checkpoint names -> blob order of include/semcode_hip.h (sc_encoder_blob_bytes)
+_HF_HEAD = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight",
+            "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+_HF_LAYER = ["attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+             "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
+             "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+             "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
+
+
+def load_weight_blob(path: "str | Path", layers: int) -> np.ndarray:
+    """Flat f32 blob in ABI order from `.npy` (already flat) or `.safetensors` (HF BERT names, optional "bert." prefix)."""
+    path = Path(path)
+    if path.suffix == ".npy":
+        return np.load(path, allow_pickle=False).astype(np.float32).reshape(-1)
+    if path.suffix == ".safetensors":
+        from safetensors.numpy import load_file
+
+        tensors = load_file(str(path))
+
+        def get(name: str) -> np.ndarray:
+            for key in (name, "bert." + name):
+                if key in tensors:
+                    return np.asarray(tensors[key], dtype=np.float32).reshape(-1)
+            raise KeyError(f"{path}: tensor {name!r} not found")
+
+        parts = [get(n) for n in _HF_HEAD]
+        for l in range(layers):
+            parts += [get(f"encoder.layer.{l}.{n}") for n in _HF_LAYER]
+        return np.concatenate(parts)
+    raise ValueError(f"unsupported weight file {path} (use .npy blob or .safetensors)")
+
+
+class MI355XEmbeddings:
+    """LangChain-Embeddings-shaped client whose forward runs in libsemcode_hip on the MI355X."""
+
+    def __init__(self, model: Optional[str] = None, *, cfg: Optional[dict] = None, weights: "np.ndarray | str | Path | None" = None,
+                 vocab: "dict | str | Path | None" = None, device: Optional[int] = None, max_tokens: Optional[int] = None,
+                 normalize: bool = False, batch_size: int = 256, runtime: Any = None, synth_seed: int = 0) -> None:
+        from .. import _native  # raises loudly when libsemcode_hip.so is missing: there is no CPU fallback
+
+        settings = _resolve_settings()
+        self.model = model or getattr(settings, "embedding_model", None)
+        self.max_tokens = int(max_tokens or getattr(settings, "mi355x_max_tokens", 512))
+        self.batch_size = int(batch_size)
+        self._native = _native
+        self._cfg = dict(_native.BERT_BASE)
+        self._cfg.update(cfg or {})
+        self.max_tokens = min(self.max_tokens, self._cfg["max_pos"])
+        self._owns_runtime = runtime is None
+        self._runtime = runtime or _native.Runtime(device=int(device if device is not None else getattr(settings, "mi355x_device", 0)))
+        weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
+        if isinstance(weights, (str, Path)):
+            weights = load_weight_blob(weights, self._cfg["layers"])
+        if weights is None:
+            log.warning("mi355x embeddings: no weights configured (SEMCODE_MI355X_WEIGHTS_PATH); using random-init weights seed=%d", synth_seed)
+        self._encoder = _native.Encoder(self._runtime, self._cfg, weights=weights, normalize=normalize, synth_seed=synth_seed)
+        vocab = vocab if vocab is not None else getattr(settings, "mi355x_vocab_path", None)
+        if vocab is None:
+            log.warning("mi355x embeddings: no vocab.txt configured (SEMCODE_MI355X_VOCAB_PATH); using the hash tokenizer stand-in")
+            self.tokenizer: Any = HashTokenizer(self._cfg["vocab"])
+        else:
+            self.tokenizer = WordPieceTokenizer(vocab)
+        self.dimension = self._cfg["hidden"]
+
+    # ---- LangChain Embeddings surface (lists of Python floats)
+    def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        return self.embed_documents_array(texts).tolist()
+
+    def embed_query(self, text: str) -> List[float]:
+        return self.embed_documents_array([text])[0].tolist()
+
+    # ---- array fast paths
+    def embed_documents_array(self, texts: Sequence[str]) -> np.ndarray:
+        """texts -> [n, hidden] f32; tokenise on the host, forward on the device in batches."""
+        out = np.empty((len(texts), self.dimension), dtype=np.float32)
+        for start in range(0, len(texts), self.batch_size):
+            toks = [self.tokenizer.encode(t, self.max_tokens) for t in texts[start:start + self.batch_size]]
+            ids, lens = pack(toks, getattr(self.tokenizer, "pad_id", 0), self.max_tokens)
+            out[start:start + len(toks)] = self._encoder.embed_ids(ids, lens)
+        return out
+
+    def embed_ids_array(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
+        """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512), lens [B] -> [B, hidden] f32."""
+        return self._encoder.embed_ids(ids, lens)
+
+    def close(self) -> None:
+        self._encoder.close()
+        if self._owns_runtime:
+            self._runtime.close()
+
+
+class EmbeddingProviderFactory:
+    """Factory that returns embedding clients based on configuration."""
+
+    @staticmethod
+    def create(provider: "str | None" = None, model: "str | None" = None) -> Any:
+        settings = _resolve_settings()
+        provider_name = (provider or settings.embedding_provider).lower()
+
+        if provider_name in MI355X_PROVIDER_NAMES:
+            embed_model = model or settings.embedding_model
+            log.info("initializing_mi355x_embeddings model=%s", embed_model)
+            return MI355XEmbeddings(model=embed_model)
+
+        if provider_name in {"openai", "lmstudio"} or provider_name.startswith("openai"):
+            from langchain_openai import OpenAIEmbeddings  # type: ignore
+
+            embed_model = model or settings.embedding_model
+            kwargs: dict[str, Any] = {"model": embed_model, "encoding_format": "float"}
+            if settings.embedding_api_base:
+                kwargs["base_url"] = settings.embedding_api_base
+            if settings.embedding_api_key:
+                kwargs["api_key"] = settings.embedding_api_key
+            if provider_name != "openai" or not settings.embedding_use_tiktoken:
+                kwargs["tiktoken_enabled"] = False
+            return OpenAIEmbeddings(**kwargs)
+
+        if provider_name == "jina":
+            from langchain_community.embeddings import JinaEmbeddings  # type: ignore
+
+            embed_model = model or settings.embedding_model or "jina-embeddings-v2-base-en"
+            jina_kwargs: dict[str, Any] = {"model_name": embed_model}
+            if settings.embedding_api_key:
+                jina_kwargs["jina_api_key"] = settings.embedding_api_key
+            return JinaEmbeddings(**jina_kwargs)
+
+        if provider_name in {"llamacpp", "llama.cpp"}:
+            try:
+                from langchain_community.embeddings import LlamaCppEmbeddings  # type: ignore
+            except ImportError as exc:  # pragma: no cover - optional dependency
+                raise RuntimeError(
+                    "llama-cpp-python is required for llama.cpp embeddings. "
+                    "Install it or select a different embedding provider."
+                ) from exc
+            model_path = settings.embedding_llamacpp_model_path
+            if not model_path:
+                raise ValueError("Set SEMCODE_EMBEDDING_LLAMACPP_MODEL_PATH when using the llama.cpp embedding provider.")
+            return LlamaCppEmbeddings(model_path=str(model_path), n_ctx=settings.embedding_llamacpp_n_ctx,
+                                      n_threads=settings.embedding_llamacpp_n_threads, n_batch=settings.embedding_llamacpp_batch_size,
+                                      n_gpu_layers=0, verbose=False)
+
+        raise NotImplementedError(f"Embedding provider not yet supported: {provider_name}")

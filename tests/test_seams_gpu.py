@@ -1,0 +1,78 @@
+"""GPU: the two seams end to end -- factory -> embed -> payloads -> upsert -> search -> hits.
+
+Port of the reference's integration pattern (tests/integration/test_indexer_service.py:32-68 and the
+consumer loop of src/semcode/rag/pipeline.py:112-169) onto the real device classes."""
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from semcode_amd.embeddings import EmbeddingPayload, EmbeddingProviderFactory
+from semcode_amd.embeddings.providers import MI355XEmbeddings
+from semcode_amd.services import build_payloads
+from semcode_amd.storage import MilvusVectorStore
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(vocab=2000, hidden=128, layers=2, heads=2, ffn=256, max_pos=128)
+
+
+@dataclass
+class Chunk:
+    content: str
+    path: Path
+    language: str
+    start_line: int
+    end_line: int
+    symbol: str | None = None
+
+
+def test_factory_returns_device_provider(rt, monkeypatch):
+    monkeypatch.setenv("SEMCODE_EMBEDDING_PROVIDER", "mi355x")
+    emb = EmbeddingProviderFactory.create(provider="mi355x")
+    assert isinstance(emb, MI355XEmbeddings) and emb.dimension == 768
+    v = emb.embed_query("def greet(name): return name")
+    assert isinstance(v, list) and len(v) == 768 and all(isinstance(x, float) for x in v[:4])
+    emb.close()
+
+
+def test_embed_store_search_round_trip(rt):
+    emb = MI355XEmbeddings(cfg=SMALL, runtime=rt, synth_seed=3)
+    root = Path("/w/demo")
+    texts = [f"def f{i}(x):\n    return x + {i}  # helper number {i}" for i in range(150)]
+    chunks = [Chunk(t, root / "src" / f"m{i % 7}.py", "python", i + 1, i + 3) for i, t in enumerate(texts)]
+    seen = []
+    payloads = build_payloads("demo", root, chunks, emb, progress=lambda a, b: seen.append((a, b)))
+    assert seen == [(0, 150), (64, 150), (128, 150), (150, 150)]
+    assert len(payloads[0].vector) == 128 and isinstance(payloads[0].vector[0], float)
+    # list API == array fast path
+    assert np.array_equal(np.asarray([p.vector for p in payloads[:10]], np.float32), emb.embed_documents_array(texts[:10]))
+
+    store = MilvusVectorStore(collection_name="test_semcode_chunks", dim=128, runtime=rt)
+    with pytest.raises(RuntimeError):
+        store.search(payloads[0].vector)
+    store.connect()
+    up = []
+    store.upsert_embeddings(payloads, progress=lambda a, b: up.append((a, b)))
+    assert up == [(0, 150), (128, 150), (150, 150)] and len(store) == 150
+    # a document retrieves itself first under IP? not guaranteed (unnormalised) -> check with cosine store below;
+    # here: the hit list is well formed, best first, and re-ingest is idempotent (same md5 ids -> overwrite)
+    hits = next(iter(store.search(emb.embed_query(texts[17]), top_k=5)))
+    assert len(hits) == 5 and hits[0].distance >= hits[-1].distance
+    assert hits[0].entity.get("repo") == "demo" and hits[0].entity.get("metadata")["language"] == "python"
+    store.upsert_embeddings(payloads)
+    assert len(store) == 150
+    store.close()
+
+    cos = MilvusVectorStore(dim=128, metric="COSINE", index_type="FLAT", runtime=rt)
+    cos.connect()
+    cos.upsert_embeddings(payloads)
+    for i in (0, 17, 149):
+        top = next(iter(cos.search(payloads[i].vector, top_k=3)))
+        assert top[0].id == payloads[i].id and top[0].entity.get("text") == texts[i]
+        assert top[0].score == pytest.approx(1.0, abs=1e-5)
+    d, r = cos.search_batch(np.asarray([p.vector for p in payloads[:40]], np.float32), top_k=1)
+    assert r[:, 0].tolist() == list(range(40))
+    cos.close()
+    emb.close()

@@ -1,0 +1,76 @@
+"""CPU: the host tokenizer against transformers' BertTokenizer on a synthetic vocabulary, and the factory's dispatch."""
+import numpy as np
+import pytest
+
+from semcode_amd.embeddings import EmbeddingProviderFactory
+from semcode_amd.embeddings.tokenizer import HashTokenizer, WordPieceTokenizer, basic_split, bucket_for, pack
+
+WORDS = ["def", "return", "class", "self", "print", "hello", "world", "name", "str", "int", "for", "in", "range", "if", "else",
+         "greet", "the", "quick", "brown", "fox", "jump", "##s", "##ed", "##ing", "##er", "un", "##believ", "##able", "cafe", "##x",
+         "f", "x", "y", "a", "b", "c", "0", "1", "2", "10", "##0", "_", "(", ")", ":", ",", ".", "=", "+", "-", ">", "\"", "'", "{", "}",
+         "[", "]", "#", "中", "文", "naive", "resume", "##_", "__", "init", "##__"]
+
+
+@pytest.fixture(scope="module")
+def vocab_file(tmp_path_factory):
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + WORDS
+    p = tmp_path_factory.mktemp("vocab") / "vocab.txt"
+    p.write_text("\n".join(toks) + "\n", encoding="utf-8")
+    return p
+
+
+TEXTS = [
+    'def greet(name: str) -> str:\n    return f"Hello {name}"\n',
+    "The quick brown fox jumps, jumped; jumping... unbelievable!",
+    "class A(B):\n\tdef __init__(self):\n\t\tself.x = 10 + y[0]",
+    "café naïve résumé 中文 mixed space​ zero-width",
+    "",
+    "x" * 150 + " ok",
+    "for i in range(10): print(i) # comment",
+]
+
+
+def test_wordpiece_matches_transformers(vocab_file):
+    transformers = pytest.importorskip("transformers")
+    hf = transformers.BertTokenizer(str(vocab_file), do_lower_case=True)
+    mine = WordPieceTokenizer(vocab_file)
+    for t in TEXTS:
+        want = hf.encode(t, add_special_tokens=True, truncation=True, max_length=64)
+        assert mine.encode(t, 64) == want, t
+    long = " ".join(["hello world"] * 300)
+    assert mine.encode(long, 32) == hf.encode(long, add_special_tokens=True, truncation=True, max_length=32)
+
+
+def test_basic_split_and_hash_tokenizer_are_deterministic():
+    assert basic_split("Hello, World! x=1") == ["hello", ",", "world", "!", "x", "=", "1"]
+    h = HashTokenizer(30522)
+    a, b = h.encode("def greet(name): return name"), h.encode("def greet(name): return name")
+    assert a == b and a[0] == 101 and a[-1] == 102 and all(0 <= i < 30522 for i in a)
+    assert h.encode("") == [101, 102]
+
+
+def test_pack_buckets():
+    assert [bucket_for(n) for n in (1, 32, 33, 64, 200, 256, 257, 512, 9999)] == [32, 32, 64, 64, 256, 256, 512, 512, 512]
+    assert bucket_for(300, max_tokens=256) == 256
+    ids, lens = pack([[5, 6, 7], list(range(40))], pad_id=0)
+    assert ids.shape == (2, 64) and lens.tolist() == [3, 40] and ids[0, 3:].sum() == 0 and ids.dtype == np.int32
+    ids, lens = pack([list(range(700))], max_tokens=512)
+    assert ids.shape == (1, 512) and lens.tolist() == [512]
+
+
+def test_factory_dispatch_and_error_types(monkeypatch):
+    # reference providers.py:102-104
+    with pytest.raises(NotImplementedError, match="Embedding provider not yet supported: nope"):
+        EmbeddingProviderFactory.create(provider="nope")
+    # reference providers.py:79-82: llama.cpp path unset -> ValueError (when langchain_community is importable),
+    # or the RuntimeError of providers.py:73-76 when it is not
+    with pytest.raises((ValueError, RuntimeError)):
+        EmbeddingProviderFactory.create(provider="llamacpp")
+    # the MI355X provider needs the device: without one the error surfaces (no silent CPU fallback)
+    import torch
+
+    if not torch.cuda.is_available():
+        from semcode_amd import _native
+
+        with pytest.raises(_native.ScError):
+            EmbeddingProviderFactory.create(provider="mi355x")
