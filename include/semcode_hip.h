@@ -167,6 +167,14 @@ sc_status sc_index_search(sc_index* ix, const float* q, int32_t Q, int32_t k, in
 sc_status sc_index_search_dev(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe,
                               float* out_dist_dev, int64_t* out_rows_dev);
 
+/* Search path selection.  mode 0 (default): exact f32 scan for <= 16 queries, bf16-MFMA coarse scan +
+ * exact f32 re-rank + certificate (uncertified queries re-run exactly) for larger batches with
+ * k <= 32 -- both return identical results; 1: exact scan only; 2: batched path whenever supported. */
+sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode);
+/* After a search: which path ran (1 exact, 2 batched) and how many queries the batched path had to
+ * re-run through the exact scan because their certificate failed. */
+sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified);
+
 /* Multi-GPU final step (one process per GPU): merge `lists` per-shard results
  * dist [lists,Q,k] / rows [lists,Q,k] (as produced by sc_index_search* on each shard and
  * all-gathered over RCCL) into the global best-first [Q,k], same tie rule.  Host buffers. */

@@ -75,6 +75,8 @@ SIGNATURES = {
     "sc_index_fill_synthetic": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
     "sc_index_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_search_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_topk_merge_host": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -237,6 +239,15 @@ class Index:
         _check(lib().sc_index_search(self.handle, q.ctypes.data_as(C.c_void_p), Q, int(k), int(nprobe),
                                      dist.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p)))
         return dist, rows
+
+    def set_search_mode(self, mode: str) -> None:
+        """'auto' | 'exact' | 'batched' (see sc_index_set_search_mode)."""
+        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2}[mode]))
+
+    def last_search_stats(self) -> dict:
+        path, unc = C.c_int32(), C.c_int32()
+        _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
+        return {"path": {0: "none", 1: "exact", 2: "batched"}[path.value], "uncertified": unc.value}
 
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
         """Device-pointer variant (asynchronous on the runtime's stream)."""

@@ -211,6 +211,10 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->qnorm);
     hipFree(ix->partial);
     hipFree(ix->io);
+    hipFree(ix->Xb);
+    hipFree(ix->xnorm_max);
+    hipFree(ix->bscratch);
+    hipFree(ix->fb);
     delete ix;
     return SC_OK;
 }
@@ -294,7 +298,7 @@ extern "C" sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n) {
     }
     ix->n += n;
     ix->trained = false;
-    return SC_OK;
+    return SC_OK;  // rows [shadow_rows, n) get their bf16 shadow lazily
 }
 
 extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n) {
@@ -319,6 +323,7 @@ extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const i
         SC_HIP(hipStreamSynchronize(s));
     }
     ix->trained = false;
+    ix->shadow_rows = 0;  // overwritten rows invalidate the bf16 shadow
     return SC_OK;
 }
 
@@ -354,11 +359,12 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     SC_HIP(hipGetLastError());
     ix->n = n;
     ix->trained = false;
+    ix->shadow_rows = 0;
     return SC_OK;
 }
 
 // q_dev: tight [Q, dim] device; outputs device.  Caller holds ix->mu.
-static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
                                    int64_t* out_rows) {
     (void)nprobe;
     sc_runtime* rt = ix->rt;
@@ -388,6 +394,148 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
     }
     SC_HIP(hipGetLastError());
+    ix->last_path = 1;
+    return SC_OK;
+}
+
+
+// ---- batched path (scan_batched.hip): bf16 shadow + coarse GEMM phases + exact re-rank + certified fallback
+
+static sc_status ensure_shadow(sc_index* ix) {
+    hipStream_t s = ix->rt->stream;
+    const int64_t rows_pad = (ix->n + 127) / 128 * 128;
+    const size_t need = (size_t)rows_pad * ix->ld * 2;
+    if (need > ix->xb_cap) {
+        SC_HIP(hipStreamSynchronize(s));
+        hipFree(ix->Xb);
+        ix->Xb = nullptr;
+        ix->xb_cap = 0;
+        const size_t cap_rows = (size_t)((ix->capacity + 127) / 128 * 128);
+        const size_t want = std::max(need, cap_rows * ix->ld * 2);
+        hipError_t e = hipMalloc(&ix->Xb, want);
+        if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc bf16 shadow (%zu B) failed: %s", want, hipGetErrorString(e));
+        ix->xb_cap = want;
+        ix->shadow_rows = 0;
+    }
+    if (!ix->xnorm_max) {
+        hipError_t e = hipMalloc((void**)&ix->xnorm_max, 16);
+        if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+        ix->shadow_rows = 0;
+    }
+    if (ix->shadow_rows < ix->n) {
+        sc_launch_shadow(ix->X, ix->shadow_rows, ix->n - ix->shadow_rows, ix->ld, ix->Xb, s);
+        if (rows_pad > ix->n)  // the last 128-row tile reads these rows: keep them finite
+            SC_HIP(hipMemsetAsync((char*)ix->Xb + (size_t)ix->n * ix->ld * 2, 0, (size_t)(rows_pad - ix->n) * ix->ld * 2, s));
+        sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max, s);
+        ix->shadow_rows = ix->n;
+        SC_HIP(hipGetLastError());
+    }
+    return SC_OK;
+}
+
+static const int BATCH_CAP = 4096;        // survivors kept per query and phase
+static const int64_t PHASE0_ROWS = 1024;  // first phase; each next phase covers 16x more rows
+
+static bool batched_applicable(const sc_index* ix, int Q, int k) {
+    if (ix->search_mode == 1) return false;
+    if (k > sc_batched_kprime() / 2 || ix->n < 1) return false;
+    if (ix->search_mode == 2) return true;
+    return Q > 16 && ix->n >= 4096;
+}
+
+static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    const int metric = (int)ix->metric, ld = ix->ld, KP = sc_batched_kprime();
+    const int Qpad = (Q + 127) / 128 * 128;
+    sc_status st = ensure_shadow(ix);
+    if (st) return st;
+    st = grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
+    if (st) return st;
+    st = grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    if (st) return st;
+    // scratch layout
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_qb = carve((size_t)Qpad * ld * 2), o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4),
+                 o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8),
+                 o_surv = carve((size_t)Q * BATCH_CAP * 8);
+    st = grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
+    if (st) return st;
+    char* b = (char*)ix->bscratch;
+    void* Qb = b + o_qb;
+    float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
+    unsigned* cnt = (unsigned*)(b + o_cnt);
+    int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
+    uint64_t *best = (uint64_t*)(b + o_best), *surv = (uint64_t*)(b + o_surv);
+
+    sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
+    sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, s);
+    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, s);
+    int64_t r0 = 0, span = PHASE0_ROWS;
+    while (r0 < ix->n) {
+        const int64_t r1 = std::min(ix->n, r0 + span);
+        hipEvent_t e0, e1;
+        sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+        sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s);
+        sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+        sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+        sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, s);
+        sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+        r0 = r1;
+        span *= 16;
+    }
+    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, ovf, Q, k, ix->row_base, out_dist,
+                          out_rows, flags, s);
+    SC_HIP(hipGetLastError());
+    // uncertified queries (rare): redo them with the exact scan
+    std::vector<int> hflags(Q);
+    SC_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)Q * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    std::vector<int> redo;
+    for (int i = 0; i < Q; ++i)
+        if (hflags[i]) redo.push_back(i);
+    ix->last_uncertified = (int)redo.size();
+    if (!redo.empty()) {
+        const int R = (int)redo.size();
+        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
+        st = grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
+        if (st) return st;
+        float* fq = (float*)ix->fb;
+        float* fd = (float*)((char*)ix->fb + qb);
+        int64_t* fr = (int64_t*)((char*)ix->fb + qb + db);
+        for (int j = 0; j < R; ++j)
+            SC_HIP(hipMemcpyAsync(fq + (size_t)j * ix->dim, q_dev + (size_t)redo[j] * ix->dim, (size_t)ix->dim * 4, hipMemcpyDeviceToDevice, s));
+        st = search_exact_locked(ix, fq, R, k, 0, fd, fr);
+        if (st) return st;
+        for (int j = 0; j < R; ++j) {
+            SC_HIP(hipMemcpyAsync(out_dist + (size_t)redo[j] * k, fd + (size_t)j * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+            SC_HIP(hipMemcpyAsync(out_rows + (size_t)redo[j] * k, fr + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    ix->last_path = 2;
+    return SC_OK;
+}
+
+static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+                                   int64_t* out_rows) {
+    ix->last_uncertified = 0;
+    if (batched_applicable(ix, Q, k)) return search_batched_locked(ix, q_dev, Q, k, out_dist, out_rows);
+    return search_exact_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+}
+
+extern "C" sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode) {
+    if (!ix || mode < 0 || mode > 2) return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact) or 2 (batched)");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->search_mode = mode;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (path) *path = ix->last_path;
+    if (uncertified) *uncertified = ix->last_uncertified;
     return SC_OK;
 }
 

@@ -81,3 +81,18 @@ void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_
 // partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k,
                           int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
+
+// scan_batched.hip: bf16 shadow, coarse GEMM + filter phases, selection, exact re-rank
+int sc_batched_kprime(void);
+void sc_launch_shadow(const float* X, int64_t first, int64_t n, int ld, void* Xb, hipStream_t s);
+void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s);
+void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, hipStream_t s);
+void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, hipStream_t s);
+void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
+                           const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
+                           int cap, hipStream_t s);
+void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
+                           float* thr_fast, int* overflow, int Q, hipStream_t s);
+void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
+                           const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
+                           float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);

@@ -52,5 +52,14 @@ struct sc_index {
     float* qnorm = nullptr;  size_t qnorm_cap = 0;
     uint64_t* partial = nullptr; size_t partial_cap = 0;
     void* io = nullptr;      size_t io_cap = 0;
+    // batched path: bf16 shadow of X (rows padded to 128), per-batch scratch
+    void* Xb = nullptr;      size_t xb_cap = 0;   // bytes
+    int64_t shadow_rows = 0;                      // rows [0, shadow_rows) of Xb are valid
+    unsigned* xnorm_max = nullptr;                // device: bits of max |x|^2
+    void* bscratch = nullptr; size_t bscratch_cap = 0;
+    void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results)
+    int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported
+    int last_path = 0;                            // 1 exact, 2 batched
+    int last_uncertified = 0;
     std::mutex mu;
 };

@@ -1,0 +1,335 @@
+// scan_batched.hip -- large query batches: bf16 MFMA coarse scores fused with threshold filtering, then an
+// exact f32 re-rank with a per-query certificate (gfx950).
+//
+// Replaces (reference): the server side of Collection.search for a FLAT scan
+// (src/semcode/storage/milvus_store.py:141-147), for batches the reference never sends (it issues one
+// query per call); BASELINE.json's configs[2] (batch-1024 over 10M x 768) is this path.
+//
+// Why two stages: at Q = 1024 the scan is 2*N*d*Q = 1.6e13 FLOP per batch -- 101 ms on the f32 matrix
+// pipe but 6.3 ms at the bf16 MFMA peak, against 4.9 ms to stream the f32 corpus.
+// So the corpus keeps a bf16 shadow copy in HBM and the batch runs as a bf16 GEMM (gemm_tile.h) whose
+// epilogue never stores scores: it compares each of them with a per-query threshold and appends the
+// rare survivors (64-bit key = coarse score | row) to a per-query list.  Thresholds tighten between
+// "phases" of geometrically growing row ranges (1 Ki, 16 Ki, 256 Ki, 4 Mi, ... rows): after each phase a
+// small kernel keeps the k' best coarse keys per query and publishes the new threshold.
+//
+// Exactness: the k' (= 64) coarse candidates of a query are re-scored in f32 in the canonical
+// summation order of scan_exact.hip / oracle/sc_oracle.c, so every returned distance is bit-identical
+// to the exact path.  |coarse - exact| <= eps_q (bf16 input rounding, bound below), therefore a row that
+// is NOT a candidate has exact score >= tau_q - eps_q; if the k-th exact candidate score is strictly
+// below that, the top-k is proven complete and correctly ordered.  Queries that fail the test (or whose
+// survivor list overflowed) are flagged and re-run through the exact scan by the host code.
+//
+// Roofline: MFMA bf16; algorithmic FLOPs = 2 * rows * ld * Qpad per phase launch.
+#include "gemm_tile.h"
+
+#define KPRIME 64          // coarse candidates kept per query
+#define SEL_THREADS 256
+
+// ------------------------------------------------------------------ bf16 shadow + max norm
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ X, int64_t first, int64_t n, int ld, bf16_t* __restrict__ Xb) {
+    const int64_t total = n * (int64_t)(ld / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(X + first * ld + i * 4);
+        u16x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = f32_to_bf16(v[c]);
+        *reinterpret_cast<u16x4*>(Xb + first * ld + i * 4) = o;
+    }
+}
+__global__ __launch_bounds__(256) void norm_max_kernel(const float* __restrict__ xnorm, int64_t n, unsigned* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, xnorm[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bits
+}
+// f32 padded queries [Q, ld] -> bf16 [Qpad, ld] (rows >= Q zero)
+__global__ __launch_bounds__(256) void query_bf16_kernel(const float* __restrict__ Qp, int Q, int Qpad, int ld, bf16_t* __restrict__ Qb) {
+    const int64_t total = (int64_t)Qpad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        Qb[i] = (i / ld) < Q ? f32_to_bf16(Qp[i]) : (bf16_t)0;
+}
+
+// ------------------------------------------------------------------ coarse GEMM + filter
+struct CoarseArgs {
+    const bf16_t* Xb;      // [rows padded to 128, ld]
+    const float* xnorm;    // [n]
+    int64_t row0, row1;    // phase row range [row0, row1), row0 % 128 == 0
+    int ld;
+    const bf16_t* Qb;      // [Qpad, ld]
+    const float* qnorm;    // [Q]
+    int Q, qtiles;
+    const float* thr;      // [Q] threshold in v-space (v = score for L2, -score otherwise), +inf at start
+    const float* thr_fast; // [Q] pre-adjusted threshold of the cheap test (superset of v <= thr)
+    uint64_t* surv;        // [Q][cap]
+    unsigned* count;       // [Q]
+    int cap;
+    int ntiles;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;  // consecutive tiles share the corpus row panel
+    const int64_t m0 = a.row0 + (int64_t)rt * G_BM;
+    const int n0 = qt * G_BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile_mainloop(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+
+    // acc[ni][mi][r] = <x[m0 + wm*64 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
+    const int fr = lane & 15, fq = lane >> 4;
+    float xn[4], xs[4];
+    int64_t rows[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        rows[mi] = m0 + wm * 64 + mi * 16 + fr;
+        xn[mi] = rows[mi] < a.row1 ? a.xnorm[rows[mi]] : 0.f;
+        xs[mi] = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn[mi]) : 0.f;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int q0 = n0 + wn * 64 + ni * 16 + 4 * fq;
+        if (q0 >= a.Q) continue;
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(a.thr_fast + q0);  // thr_fast is allocated padded to 128
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (rows[mi] >= a.row1) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dot = acc[ni][mi][r];
+                float t;
+                if (METRIC == SC_METRIC_L2) t = fmaf(-2.0f, dot, xn[mi]);
+                else if (METRIC == SC_METRIC_COSINE) t = -dot * xs[mi];
+                else t = -dot;
+                if (t <= tf[r]) {
+                    const int q = q0 + r;
+                    if (q < a.Q) {
+                        const float sc = sc_score<METRIC>(dot, xn[mi], a.qnorm[q]);
+                        const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
+                        if (v <= a.thr[q]) {
+                            const unsigned pos = atomicAdd(a.count + q, 1u);
+                            if (pos < (unsigned)a.cap) a.surv[(size_t)q * a.cap + pos] = sc_make_key<METRIC>(sc, (uint32_t)rows[mi]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ per-phase selection: keep the KPRIME best coarse keys
+// best [Q][KPRIME] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
+template <int METRIC>
+__global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __restrict__ surv, unsigned* __restrict__ count, int cap,
+                                                                   uint64_t* __restrict__ best, const float* __restrict__ qnorm,
+                                                                   float* __restrict__ thr, float* __restrict__ thr_fast,
+                                                                   int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + KPRIME] candidates, [KPRIME] output
+    uint64_t* cand = sel_lds;
+    uint64_t* outk = sel_lds + cap + KPRIME;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    unsigned c = count[q];
+    if (c > (unsigned)cap) {
+        if (tid == 0) overflow[q] = 1;
+        c = cap;
+    }
+    const int n = (int)c + KPRIME;
+    for (int i = tid; i < (int)c; i += SEL_THREADS) cand[i] = surv[(size_t)q * cap + i];
+    for (int i = tid; i < KPRIME; i += SEL_THREADS) {
+        cand[c + i] = best[(size_t)q * KPRIME + i];
+        outk[i] = SC_KEY_MAX;
+    }
+    __syncthreads();
+    // rank sort; keys are unique except for the SC_KEY_MAX padding, which never ranks below a real key
+    for (int e = tid; e < n; e += SEL_THREADS) {
+        const uint64_t key = cand[e];
+        if (key == SC_KEY_MAX) continue;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (cand[j] < key) ? 1 : 0;
+        if (rank < KPRIME) outk[rank] = key;
+    }
+    __syncthreads();
+    for (int i = tid; i < KPRIME; i += SEL_THREADS) best[(size_t)q * KPRIME + i] = outk[i];
+    if (tid == 0) {
+        count[q] = 0;
+        const uint64_t kth = outk[KPRIME - 1];
+        float t = __builtin_inff(), tf = __builtin_inff();
+        if (kth != SC_KEY_MAX) {
+            const float sc = sc_key_score(METRIC, kth);
+            t = (METRIC == SC_METRIC_L2) ? sc : -sc;
+            const float slack = 1e-3f * fabsf(t) + 1e-6f;
+            const float qn = qnorm[q];
+            if (METRIC == SC_METRIC_L2) tf = (t - qn) + slack + 1e-3f * fabsf(qn);
+            else if (METRIC == SC_METRIC_COSINE) tf = (t + slack) * sqrtf(qn) + 1e-5f * sqrtf(qn);  // -dot/|x| <= (t+slack)*|q|  (|q| > 0)
+            else tf = t + slack;
+        }
+        thr[q] = t;
+        thr_fast[q] = tf;
+    }
+}
+
+// ------------------------------------------------------------------ exact re-rank + certificate
+// One wave per query: lane j re-scores candidate j with the canonical f32 fmaf chain.
+template <int METRIC>
+__global__ __launch_bounds__(64) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
+                                                          const float* __restrict__ Qp, const float* __restrict__ qnorm,
+                                                          const uint64_t* __restrict__ best, const float* __restrict__ thr,
+                                                          const unsigned* __restrict__ xnorm_max_bits, const int* __restrict__ overflow, int k,
+                                                          int64_t row_base, float* __restrict__ out_dist, int64_t* __restrict__ out_rows,
+                                                          int* __restrict__ flags) {
+    __shared__ uint64_t keys[KPRIME];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t ck = best[(size_t)q * KPRIME + lane];
+    uint64_t ek = SC_KEY_MAX;
+    if (ck != SC_KEY_MAX) {
+        const uint32_t row = (uint32_t)ck;
+        const float* x = X + (size_t)row * ld;
+        const float* qv = Qp + (size_t)q * ld;
+        float acc = 0.f;
+        for (int t = 0; t < ld; t += 16) {
+            f32x4 xa[4], qa[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xa[g] = *reinterpret_cast<const f32x4*>(x + t + 4 * g);
+                qa[g] = *reinterpret_cast<const f32x4*>(qv + t + 4 * g);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc = fmaf(xa[g][c], qa[g][c], acc);
+        }
+        ek = sc_make_key<METRIC>(sc_score<METRIC>(acc, xnorm[row], qnorm[q]), row);
+    }
+    keys[lane] = ek;
+    __syncthreads();
+    int rank = 0;
+    int have = 0;
+    for (int j = 0; j < KPRIME; ++j) {
+        const uint64_t o = keys[j];
+        rank += (o < ek) ? 1 : 0;
+        have += (o != SC_KEY_MAX) ? 1 : 0;
+    }
+    __syncthreads();
+    if (ek != SC_KEY_MAX) keys[rank] = ek;  // unique keys -> a permutation of the first `have` slots
+    __syncthreads();
+    if (lane < k) {
+        const size_t o = (size_t)q * k + lane;
+        if (lane < have) {
+            out_dist[o] = sc_key_score(METRIC, keys[lane]);
+            out_rows[o] = row_base + (int64_t)(uint32_t)keys[lane];
+        } else {
+            out_dist[o] = (METRIC == SC_METRIC_L2) ? __builtin_inff() : -__builtin_inff();
+            out_rows[o] = -1;
+        }
+    }
+    if (lane == 0) {
+        int bad = overflow[q];
+        if (have == KPRIME) {  // otherwise every row of the corpus is a candidate: nothing can be missing
+            const float u = 0.00390625f;                       // bf16 unit roundoff 2^-8
+            const float C = 2.0f * u + u * u + (float)ld * 1.2e-7f;  // input rounding + f32 accumulation
+            const float xmax = sqrtf(__builtin_bit_cast(float, *xnorm_max_bits));
+            const float qn = sqrtf(qnorm[q]);
+            float eps;
+            if (METRIC == SC_METRIC_L2) eps = 2.0f * C * xmax * qn;
+            else if (METRIC == SC_METRIC_COSINE) eps = C;
+            else eps = C * xmax * qn;
+            eps = eps * 1.01f + 1e-6f;
+            const int kk = k < have ? k : have;
+            const float sc = sc_key_score(METRIC, keys[kk - 1]);
+            const float vk = (METRIC == SC_METRIC_L2) ? sc : -sc;
+            if (!(vk + eps < thr[q])) bad = 1;
+        }
+        flags[q] = bad;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_batched_init_kernel(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count,
+                                                                 int* overflow, int Q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < qpad) { thr[i] = __builtin_inff(); thr_fast[i] = __builtin_inff(); }
+    if (i < Q) { count[i] = 0u; overflow[i] = 0; }
+    if (i < Q * KPRIME) best[i] = SC_KEY_MAX;
+}
+
+// ------------------------------------------------------------------ launchers
+void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, hipStream_t s) {
+    const int n = Q * KPRIME > qpad ? Q * KPRIME : qpad;
+    hipLaunchKernelGGL(scan_batched_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, thr, thr_fast, qpad, best, count, overflow, Q);
+}
+void sc_launch_shadow(const float* X, int64_t first, int64_t n, int ld, void* Xb, hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n * (ld / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, first, n, ld, (bf16_t*)Xb);
+}
+void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s) {
+    hipMemsetAsync(out_bits, 0, 4, s);
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(norm_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xnorm, n, out_bits);
+}
+void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, hipStream_t s) {
+    int64_t blocks = ((int64_t)Qpad * ld + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(query_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Qp, Q, Qpad, ld, (bf16_t*)Qb);
+}
+
+int sc_batched_kprime(void) { return KPRIME; }
+
+void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
+                           const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
+                           int cap, hipStream_t s) {
+    CoarseArgs a;
+    a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
+    a.Q = Q; a.qtiles = Qpad / G_BN; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap;
+    const int64_t rtiles = (row1 - row0 + G_BM - 1) / G_BM;
+    a.ntiles = (int)(rtiles * a.qtiles);
+    const size_t lds = 4 * G_TILE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)a.ntiles), block(256);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_coarse_kernel<SC_METRIC_L2>, grid, block, lds, s, a);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_coarse_kernel<SC_METRIC_COSINE>, grid, block, lds, s, a);
+    else hipLaunchKernelGGL(scan_coarse_kernel<SC_METRIC_IP>, grid, block, lds, s, a);
+}
+
+void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
+                           float* thr_fast, int* overflow, int Q, hipStream_t s) {
+    const size_t lds = (size_t)(cap + 2 * KPRIME) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)Q), block(SEL_THREADS);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_L2>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_COSINE>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
+    else hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_IP>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
+}
+
+void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
+                           const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
+                           float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
+    dim3 grid((unsigned)Q), block(64);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
+    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
+}

@@ -1,0 +1,125 @@
+"""GPU: the batched search path (bf16 MFMA coarse scan + exact f32 re-rank + certificate) returns exactly what
+the exact scan and the CPU oracle return: ids/order exact, distances bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import sc_oracle as orc
+from semcode_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("metric", ["IP", "L2", "COSINE"])
+@pytest.mark.parametrize("nq", [17, 64, 200])
+def test_batched_equals_oracle_100k(rt, metric, nq):
+    X = orc.synth(100_000, 768, seed=31)
+    Q = orc.synth(nq, 768, seed=32)
+    ix = _native.Index(rt, 768, metric=metric)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    d, r = ix.search(Q, k=10)
+    st = ix.last_search_stats()
+    assert st["path"] == "batched"
+    od, orow = orc.search(X, Q, 10, metric)
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    assert st["uncertified"] <= nq // 4, st  # the certificate must hold for the bulk of gaussian queries
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [1, 100, 127, 128, 129, 1000, 5000])
+def test_batched_small_and_ragged(rt, n):
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 100)).astype(np.float32)
+    Q = rng.standard_normal((40, 100)).astype(np.float32)
+    ix = _native.Index(rt, 100, metric="L2", row_base=77)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    d, r = ix.search(Q, k=7)
+    assert ix.last_search_stats()["path"] == "batched"
+    od, orow = orc.search(X, Q, 7, "L2", row_base=77)
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.close()
+
+
+def test_batched_incremental_adds_and_overwrite(rt):
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((6000, 128)).astype(np.float32)
+    Q = rng.standard_normal((33, 128)).astype(np.float32)
+    ix = _native.Index(rt, 128, metric="IP")
+    ix.set_search_mode("batched")
+    ix.add(X[:3000])
+    d, r = ix.search(Q, k=5)
+    assert np.array_equal(r, orc.search(X[:3000], Q, 5, "IP")[1])
+    ix.add(X[3000:])  # shadow must be extended
+    d, r = ix.search(Q, k=5)
+    assert np.array_equal(r, orc.search(X, Q, 5, "IP")[1])
+    X[[10, 5999]] = 3.0 * Q[[0, 1]]  # overwrite -> shadow rebuilt; these rows become the best hits
+    ix.overwrite(X[[10, 5999]], [10, 5999])
+    d, r = ix.search(Q, k=5)
+    od, orow = orc.search(X, Q, 5, "IP")
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)) and r[0, 0] == 10 and r[1, 0] == 5999
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["IP", "L2", "COSINE"])
+def test_near_duplicates_defeat_the_certificate_but_not_the_result(rt, metric):
+    # 600 rows that differ from one base vector by ~1e-4: bf16 cannot separate them, so the certificate fails
+    # and the query is re-run exactly; exact duplicates must still come back in row order.
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((8000, 256)).astype(np.float32)
+    base = rng.standard_normal(256).astype(np.float32)
+    X[1000:1600] = base + 1e-4 * rng.standard_normal((600, 256)).astype(np.float32)
+    X[1200:1210] = base
+    Q = rng.standard_normal((20, 256)).astype(np.float32)
+    Q[0] = base
+    ix = _native.Index(rt, 256, metric=metric)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    d, r = ix.search(Q, k=16)
+    st = ix.last_search_stats()
+    assert st["path"] == "batched" and st["uncertified"] >= 1
+    od, orow = orc.search(X, Q, 16, metric)
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.set_search_mode("exact")
+    d2, r2 = ix.search(Q, k=16)
+    assert np.array_equal(r2, r) and np.array_equal(bits(d2), bits(d))
+    ix.close()
+
+
+def test_auto_mode_picks_paths(rt):
+    X = orc.synth(20_000, 128, seed=3)
+    ix = _native.Index(rt, 128, metric="L2")
+    ix.add(X)
+    ix.search(orc.synth(8, 128, seed=4), k=10)
+    assert ix.last_search_stats()["path"] == "exact"
+    ix.search(orc.synth(100, 128, seed=4), k=10)
+    assert ix.last_search_stats()["path"] == "batched"
+    ix.search(orc.synth(100, 128, seed=4), k=40)  # k too large for the 64-candidate re-rank
+    assert ix.last_search_stats()["path"] == "exact"
+    ix.close()
+
+
+def test_full_size_batched_1024_queries_over_10m(rt):
+    """BASELINE config 3.  Batched result == exact-scan result on a sample of the queries; properties on all."""
+    N, D, K = 10_000_000, 768, 10
+    ix = _native.Index(rt, D, metric="L2")
+    ix.fill_synthetic(N, seed=0)
+    Q = orc.synth(1024, D, seed=1)
+    d, r = ix.search(Q, k=K)
+    st = ix.last_search_stats()
+    assert st["path"] == "batched" and st["uncertified"] <= 64, st
+    assert (np.diff(d, axis=1) >= 0).all() and ((r >= 0) & (r < N)).all()
+    # returned distances are bit-exact f32 scores of the regenerated rows
+    for qi in range(0, 1024, 97):
+        od, orow = orc.search(orc.synth_rows(r[qi], D, 0), Q[qi:qi + 1], K, "L2")
+        assert np.array_equal(bits(od[0]), bits(d[qi])) and np.array_equal(orow[0], np.arange(K))
+    # and equal to the exact HBM-bound scan on 32 of the queries
+    ix.set_search_mode("exact")
+    sel = np.arange(0, 1024, 32)
+    de, re_ = ix.search(Q[sel], k=K)
+    assert np.array_equal(re_, r[sel]) and np.array_equal(bits(de), bits(d[sel]))
+    ix.close()
