@@ -132,6 +132,10 @@ sc_status sc_encoder_embed_ids_dev(sc_encoder* enc, const int32_t* ids_dev, cons
  * M, N multiples of 128, K multiple of 64. */
 sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const float* W, const float* bias, const float* R,
                             int32_t M, int32_t N, int32_t K, float* out);
+/* Times `iters` launches of one GEMM shape on device-resident synthetic data (kernel tuning; variant 0 =
+ * the product kernel, other values = diagnostic ablations whose outputs are meaningless). */
+sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant,
+                             double* ms_per_launch);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
 sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "sc_index_destroy": (C.c_int32, [C.c_void_p]),
@@ -329,6 +330,13 @@ def diag_gemm_bf16(rt: Runtime, A, W, bias, R=None, epi: int = 0) -> np.ndarray:
     _check(lib().sc_diag_gemm_bf16(rt.handle, epi, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
                                    bias.ctypes.data_as(C.c_void_p), Rp, M, N, K, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def diag_gemm_bench(rt: Runtime, M: int, N: int, K: int, epi: int = 0, iters: int = 20, variant: int = 0) -> float:
+    """ms per launch of one GEMM shape on device-resident synthetic data (tuning aid)."""
+    ms = C.c_double()
+    _check(lib().sc_diag_gemm_bench(rt.handle, epi, M, N, K, iters, variant, C.byref(ms)))
+    return ms.value
 
 
 def diag_attention(rt: Runtime, qkv, lens, B: int, S: int, heads: int) -> np.ndarray:

@@ -79,18 +79,132 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     }
 }
 
+
+// ---- 256 x 256 x 64 tile variant (gemm_tile.h, second half); used when M % 256 == 0 and N % 256 == 0
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = mt * T_BM, n0 = nt * T_BN;
+
+    f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile256_mainloop<DBG & 3>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
+    if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
+        if (sink == 12345.678f) a.C[0] = 1;
+        return;
+    }
+    // ---- epilogue through LDS: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row
+    // segments per store instruction); staging the wave's 128 x 64 f32 block in 4 passes of 32 rows lets it
+    // leave as whole 128-byte row segments, 16 B per lane.  The pipeline buffers are free here: after the
+    // main loop's last barrier no wave reads them again.  Staging is wave-private (LDS executes a wave's
+    // instructions in order), so no barrier is needed.
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int STG_ROW = 64 * 4 + 16;  // bytes: 64 f32 + 16 B pad (conflict-free b128 writes)
+    char* stg = smem + w * (32 * STG_ROW);
+    f32x4 bias4[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+    const int prow = lane >> 3, c8 = (lane & 7) * 8;
+    const f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    (void)bz;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[ni][2 * p + h] + bias4[ni];
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                }
+                *reinterpret_cast<f32x4*>(stg + (h * 16 + fr) * STG_ROW + (ni * 16 + 4 * fq) * 4) = v;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rl = j * 8 + prow;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4 + 16);
+            const size_t m = (size_t)(m0 + wm * 128 + p * 32 + rl);
+            const int n = n0 + wn * 64 + c8;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (EPI == EPI_BIAS_RES) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.R + m * a.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += bf16_to_f32((bf16_t)rv[r]);
+            }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
+            *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = o;
+        }
+    }
+}
+
 // M, N multiples of 128; K multiple of 64; all leading dimensions multiples of 8 elements.
 bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && (M % G_BM) == 0 && (N % G_BN) == 0 && (K % G_BK) == 0; }
+
+static int g_gemm_dbg = 0;
+void sc_gemm_set_debug(int v) { g_gemm_dbg = v; }
+static bool g_force_tile128 = false;
+void sc_gemm_force_tile128(bool on) { g_force_tile128 = on; }
 
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
                          int ldc, int M, int N, int K, hipStream_t s) {
     GemmArgs a;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
+    static bool attr_done = false;
+    if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
+        a.tiles_n = N / T_BN;
+        a.ntiles = (M / T_BM) * a.tiles_n;
+        const size_t lds256 = 4 * T_TILE_BYTES;  // 128 KiB
+        static bool attr256 = false;
+        if (!attr256) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            attr256 = true;
+        }
+        dim3 grid((unsigned)a.ntiles), block(512);
+        if (g_gemm_dbg) {  // diagnostic variants (sc_diag_gemm_bench); results are meaningless
+            static bool attrd = false;
+            if (!attrd) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                attrd = true;
+            }
+            if (g_gemm_dbg == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 1>), grid, block, lds256, s, a);
+            else if (g_gemm_dbg == 2) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 2>), grid, block, lds256, s, a);
+            else if (g_gemm_dbg == 4) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 4>), grid, block, lds256, s, a);
+            else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 5>), grid, block, lds256, s, a);
+            return;
+        }
+        if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_GELU>, grid, block, lds256, s, a);
+        else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_RES>, grid, block, lds256, s, a);
+        else hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS>, grid, block, lds256, s, a);
+        return;
+    }
     a.tiles_n = N / G_BN;
     a.ntiles = (M / G_BM) * a.tiles_n;
     const size_t lds = 4 * G_TILE_BYTES;  // 64 KiB
-    static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

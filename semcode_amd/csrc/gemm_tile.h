@@ -1,6 +1,8 @@
 // gemm_tile.h -- the 128x128x64 bf16 MFMA tile machinery shared by gemm_bf16.hip (encoder GEMMs) and
 // scan_batched.hip (coarse distance GEMM).  See gemm_bf16.hip for the design notes.
 #pragma once
+#include <type_traits>
+
 #include "sc_common.h"
 
 #define G_BM 128
@@ -12,6 +14,26 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gbl_vptr;
 typedef unsigned short bf16_t;
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two f32 -> packed bf16 pair (round to nearest even, NaN preserved): one v_cvt_pk_bf16_f32
+static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2));
+}
+// erf-GELU with the Abramowitz-Stegun 7.1.26 rational erf (|abs err| <= 1.5e-7, far below bf16 resolution)
+static __device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // 1 - erf(z)
+    const float erf_abs = 1.0f - e;
+    return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
+}
 
 static __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 static __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -85,4 +107,115 @@ static __device__ __forceinline__ void gemm_tile_mainloop(const bf16_t* __restri
 static __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// =====================================================================================================
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave), 1 workgroup per CU.
+//
+// Why: the 128^2 tile moves 1 byte L2->LDS per 64 FLOP and, with one K-tile in flight, ran at the
+// latency of that fill (measured 630 TF).  This tile needs half the bytes per FLOP, keeps the NEXT TWO
+// K-tiles in flight (2 LDS buffers + the tile being consumed lives in registers) and overlaps every LDS
+// fragment read with MFMAs:
+//
+//     F0 = fragments of k-step 0 of tile t (already in registers)
+//     loop t:  issue ds_reads  F1 <- k-step 1 of tile t            (LDS[t&1])
+//              32 MFMAs on F0
+//              wait my LDS reads (F1) and my LDS-DMA of tile t+1;  ONE barrier
+//                    -> every wave is done with LDS[t&1] and tile t+1 is visible
+//              issue LDS-DMA of tile t+2 -> LDS[t&1]               (lands during the next 64 MFMAs)
+//              issue ds_reads  F0 <- k-step 0 of tile t+1          (LDS[(t+1)&1])
+//              32 MFMAs on F1
+// =====================================================================================================
+#define T_BM 256
+#define T_BN 256
+#define T_TILE_BYTES (256 * 64 * 2)  // 32 KiB per operand tile
+
+static __device__ __forceinline__ void stage_tile256(const bf16_t* __restrict__ src, int ld, int row0, int k0, char* lds_tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;      // 32 pieces of 1 KiB, 4 per wave
+        const int p = piece * 64 + lane;  // 16-byte chunk index in the tile image
+        const int r = p >> 3, pos = p & 7;
+        const int c = pos ^ ((r >> 1) & 7);
+        const bf16_t* g = src + (size_t)(row0 + r) * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// fragments of one k-step (32 deep) for this wave: 4 W-side (MFMA A operand) + 8 A-side (MFMA B operand)
+struct Frag256 {
+    bf16x8 wf[4];
+    bf16x8 af[8];
+};
+static __device__ __forceinline__ void read_frags256(const char* At, const char* Wt, int wm, int wn, int fr, int fq, int ks, Frag256& f) {
+    const int c = 4 * ks + fq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rw = wn * 64 + i * 16 + fr;
+        f.wf[i] = *reinterpret_cast<const bf16x8*>(Wt + rw * 128 + ((c ^ ((rw >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm * 128 + i * 16 + fr;
+        f.af[i] = *reinterpret_cast<const bf16x8*>(At + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+    }
+}
+static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&acc)[4][8]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wf[ni], f.af[mi], acc[ni][mi], 0, 0, 0);
+}
+
+// acc[ni][mi][r] = sum_k A[m0 + wm*128 + mi*16 + (lane&15)][k] * W[n0 + wn*64 + ni*16 + 4*(lane>>4) + r][k]
+// smem: 128 KiB ([2][A tile | W tile]).  All 512 threads of the workgroup must call it.  K % 64 == 0.
+// DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs.
+template <int DBG = 0>
+static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
+                                                              int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane) {
+    const int wm = w >> 2, wn = w & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = K / G_BK;
+    stage_tile256(A, lda, m0, 0, smem, w, lane);
+    stage_tile256(W, ldw, n0, 0, smem + T_TILE_BYTES, w, lane);
+    if (nk > 1) {
+        stage_tile256(A, lda, m0, G_BK, smem + 2 * T_TILE_BYTES, w, lane);
+        stage_tile256(W, ldw, n0, G_BK, smem + 3 * T_TILE_BYTES, w, lane);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 (8 pieces per wave) still in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    Frag256 f0, f1;
+    read_frags256(smem, smem + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
+    // One K-tile.  STAGE: a tile kt+2 exists and is requested; NEXT: a tile kt+1 exists and its k-step-0
+    // fragments are fetched.  sched_barrier(0) pins the order hipcc would otherwise relax (it sinks the
+    // register-only MFMAs below the barrier and the LDS-DMA issue below the next MFMA block, which halves
+    // the time the DMA has to land).
+    auto ktile = [&](int kt, auto stage_c, auto next_c) {
+        constexpr bool STAGE = decltype(stage_c)::value, NEXT = decltype(next_c)::value;
+        char* cur = smem + (kt & 1) * (2 * T_TILE_BYTES);
+        char* nxt = smem + ((kt + 1) & 1) * (2 * T_TILE_BYTES);
+        read_frags256(cur, cur + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
+        if (!(DBG & 2)) mfma_frags256(f0, acc);
+        else asm volatile("" ::"v"(f0.wf[0]), "v"(f0.af[0]), "v"(f0.wf[3]), "v"(f0.af[7]));
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my LDS-DMA of tile kt+1 (issued one K-tile ago)
+        __syncthreads();                                   // + every wave's reads of `cur` are complete
+        if (STAGE && !(DBG & 1)) {
+            stage_tile256(A, lda, m0, (kt + 2) * G_BK, cur, w, lane);
+            stage_tile256(W, ldw, n0, (kt + 2) * G_BK, cur + T_TILE_BYTES, w, lane);
+        }
+        if (NEXT) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 2)) mfma_frags256(f1, acc);
+        else asm volatile("" ::"v"(f1.wf[0]), "v"(f1.af[0]), "v"(f1.wf[3]), "v"(f1.af[7]));
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 2 < nk; ++kt) ktile(kt, T{}, T{});
+    if (kt + 1 < nk) { ktile(kt, F{}, T{}); ++kt; }
+    ktile(kt, F{}, F{});
 }

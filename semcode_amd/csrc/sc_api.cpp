@@ -403,14 +403,14 @@ static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q
 
 static sc_status ensure_shadow(sc_index* ix) {
     hipStream_t s = ix->rt->stream;
-    const int64_t rows_pad = (ix->n + 127) / 128 * 128;
+    const int64_t rows_pad = (ix->n + 255) / 256 * 256;
     const size_t need = (size_t)rows_pad * ix->ld * 2;
     if (need > ix->xb_cap) {
         SC_HIP(hipStreamSynchronize(s));
         hipFree(ix->Xb);
         ix->Xb = nullptr;
         ix->xb_cap = 0;
-        const size_t cap_rows = (size_t)((ix->capacity + 127) / 128 * 128);
+        const size_t cap_rows = (size_t)((ix->capacity + 255) / 256 * 256);
         const size_t want = std::max(need, cap_rows * ix->ld * 2);
         hipError_t e = hipMalloc(&ix->Xb, want);
         if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc bf16 shadow (%zu B) failed: %s", want, hipGetErrorString(e));
@@ -424,7 +424,7 @@ static sc_status ensure_shadow(sc_index* ix) {
     }
     if (ix->shadow_rows < ix->n) {
         sc_launch_shadow(ix->X, ix->shadow_rows, ix->n - ix->shadow_rows, ix->ld, ix->Xb, s);
-        if (rows_pad > ix->n)  // the last 128-row tile reads these rows: keep them finite
+        if (rows_pad > ix->n)  // the last row tile reads these rows: keep them finite
             SC_HIP(hipMemsetAsync((char*)ix->Xb + (size_t)ix->n * ix->ld * 2, 0, (size_t)(rows_pad - ix->n) * ix->ld * 2, s));
         sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max, s);
         ix->shadow_rows = ix->n;
@@ -447,7 +447,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     sc_runtime* rt = ix->rt;
     hipStream_t s = rt->stream;
     const int metric = (int)ix->metric, ld = ix->ld, KP = sc_batched_kprime();
-    const int Qpad = (Q + 127) / 128 * 128;
+    const int Qpad = Q > 128 ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches
     sc_status st = ensure_shadow(ix);
     if (st) return st;
     st = grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);

@@ -29,6 +29,9 @@ void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s)
 void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, float offset, hipStream_t s);
 void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s);
 
+void sc_gemm_set_debug(int v);
+void sc_gemm_force_tile128(bool on);
+
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
 
 struct LayerW {
@@ -51,7 +54,7 @@ struct sc_encoder {
     size_t params_bytes = 0;
     float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *embg = nullptr, *embb = nullptr;
     std::vector<LayerW> layers;
-    // workspace for `ws_tokens` (multiple of 128) tokens
+    // workspace for `ws_tokens` (multiple of 256) tokens
     int64_t ws_tokens = 0;
     char* ws = nullptr;
     void *x = nullptr, *x1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hm = nullptr;
@@ -206,7 +209,7 @@ extern "C" sc_status sc_encoder_destroy(sc_encoder* e) {
 }
 
 static sc_status ensure_ws(sc_encoder* e, int64_t B, int64_t S) {
-    const int64_t tokens = (B * S + 127) / 128 * 128;
+    const int64_t tokens = (B * S + 255) / 256 * 256;  // GEMM tiles are 256 rows
     if (tokens <= e->ws_tokens && B <= e->ws_batch) return SC_OK;
     SC_HIP(hipStreamSynchronize(e->rt->stream));
     hipFree(e->ws);
@@ -237,7 +240,7 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
     hipStream_t s = rt->stream;
     const int H = c.hidden, F = c.ffn;
     const int tokens = B * S;
-    const int M = (tokens + 127) / 128 * 128;
+    const int M = (tokens + 255) / 256 * 256;
     sc_launch_embed_ln(ids_dev, tokens, S, H, c.vocab, c.max_pos, e->wemb, e->pemb, e->temb, e->embg, e->embb, c.ln_eps, e->x, s);
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
@@ -371,5 +374,46 @@ extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const i
     SC_HIP(hipGetLastError());
     SC_HIP(hipMemcpyAsync(out, fo.p, (size_t)tokens * H * 4, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+// Time `iters` launches of one GEMM shape on device-resident synthetic bf16 data (hipEvents on the
+// runtime's stream).  variant: 0 = product kernel; 1/2/4/5 = diagnostic ablations of the 256-tile kernel
+// (no in-loop LDS-DMA / no MFMA / no epilogue / no DMA + no epilogue); 128 = force the 128x128 tile.
+extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant,
+                                        double* ms_per_launch) {
+    if (!rt || !ms_per_launch || iters < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bench: bad argument");
+    if (!sc_gemm_bf16_supported(M, N, K)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_bench: need M%%128==0, N%%128==0, K%%64==0");
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    DevBuf fa, da, fw, dw, db, dr, dc;
+    const int64_t na = (int64_t)M * K, nw = (int64_t)N * K, nc = (int64_t)M * N;
+    if (fa.alloc(na * 4) != hipSuccess || da.alloc(na * 2) != hipSuccess || fw.alloc(nw * 4) != hipSuccess || dw.alloc(nw * 2) != hipSuccess ||
+        db.alloc((size_t)N * 4) != hipSuccess || dr.alloc(nc * 2) != hipSuccess || dc.alloc(nc * 2) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    sc_launch_synth_scaled((float*)fa.p, na, 1, 1.0f, 0.0f, s);
+    sc_launch_synth_scaled((float*)fw.p, nw, 2, 0.05f, 0.0f, s);
+    sc_launch_f32_to_bf16((const float*)fa.p, da.p, na, s);
+    sc_launch_f32_to_bf16((const float*)fw.p, dw.p, nw, s);
+    SC_HIP(hipMemsetAsync(db.p, 0, (size_t)N * 4, s));
+    SC_HIP(hipMemsetAsync(dr.p, 0, (size_t)nc * 2, s));
+    sc_gemm_force_tile128(variant == 128);
+    sc_gemm_set_debug(variant == 128 ? 0 : variant);
+    hipEvent_t e0, e1;
+    SC_HIP(hipEventCreate(&e0));
+    SC_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    hipEventRecord(e1, s);
+    hipError_t he = hipStreamSynchronize(s);
+    sc_gemm_force_tile128(false);
+    sc_gemm_set_debug(0);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (he != hipSuccess) return sc_fail(SC_ERR_HIP, "diag gemm bench failed: %s", hipGetErrorString(he));
+    *ms_per_launch = ms / iters;
     return SC_OK;
 }

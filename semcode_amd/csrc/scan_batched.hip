@@ -127,6 +127,65 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
     }
 }
 
+// 256 x 256 tile variant (gemm_tile.h, second half): 8 waves, each 128 corpus rows x 64 queries.
+template <int METRIC>
+__global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;
+    const int64_t m0 = a.row0 + (int64_t)rt * T_BM;
+    const int n0 = qt * T_BN;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile256_mainloop<0>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+
+    // acc[ni][mi][r] = <x[m0 + wm*128 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 tf[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int q0 = n0 + wn * 64 + ni * 16 + 4 * fq;  // thr_fast is allocated padded to 256 and +inf-initialised
+        tf[ni] = *reinterpret_cast<const f32x4*>(a.thr_fast + q0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int64_t row = m0 + wm * 128 + mi * 16 + fr;
+        if (row >= a.row1) continue;
+        const float xn = a.xnorm[row];
+        const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int q0 = n0 + wn * 64 + ni * 16 + 4 * fq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dot = acc[ni][mi][r];
+                float t;
+                if (METRIC == SC_METRIC_L2) t = fmaf(-2.0f, dot, xn);
+                else if (METRIC == SC_METRIC_COSINE) t = -dot * xs;
+                else t = -dot;
+                if (t <= tf[ni][r]) {
+                    const int q = q0 + r;
+                    if (q < a.Q) {
+                        const float sc = sc_score<METRIC>(dot, xn, a.qnorm[q]);
+                        const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
+                        if (v <= a.thr[q]) {
+                            const unsigned pos = atomicAdd(a.count + q, 1u);
+                            if (pos < (unsigned)a.cap) a.surv[(size_t)q * a.cap + pos] = sc_make_key<METRIC>(sc, (uint32_t)row);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ per-phase selection: keep the KPRIME best coarse keys
 // best [Q][KPRIME] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
 template <int METRIC>
@@ -292,7 +351,25 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
                            int cap, hipStream_t s) {
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
-    a.Q = Q; a.qtiles = Qpad / G_BN; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap;
+    a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap;
+    if ((Qpad % T_BN) == 0 && (row0 % T_BM) == 0) {  // large batches: 256 x 256 tiles (corpus rows are padded to 256)
+        a.qtiles = Qpad / T_BN;
+        a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);
+        const size_t lds256 = 4 * T_TILE_BYTES;
+        static bool attr256 = false;
+        if (!attr256) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            attr256 = true;
+        }
+        dim3 grid256((unsigned)a.ntiles), block256(512);
+        if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_L2>, grid256, block256, lds256, s, a);
+        else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_COSINE>, grid256, block256, lds256, s, a);
+        else hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_IP>, grid256, block256, lds256, s, a);
+        return;
+    }
+    a.qtiles = Qpad / G_BN;
     const int64_t rtiles = (row1 - row0 + G_BM - 1) / G_BM;
     a.ntiles = (int)(rtiles * a.qtiles);
     const size_t lds = 4 * G_TILE_BYTES;

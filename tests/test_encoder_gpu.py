@@ -31,7 +31,8 @@ def gelu(x):
 
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 768, 3072)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 768, 3072),  # 128x128 tiles
+                                   (256, 256, 64), (256, 256, 128), (512, 768, 768), (256, 768, 3072), (1024, 2304, 192)])  # 256x256 tiles
 def test_gemm_kernel(rt, epi, shape):
     M, N, K = shape
     rng = np.random.default_rng(M + N + K + epi)
