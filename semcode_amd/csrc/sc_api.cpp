@@ -434,7 +434,7 @@ static sc_status ensure_shadow(sc_index* ix) {
 }
 
 static const int BATCH_CAP = 4096;        // survivors kept per query and phase
-static const int64_t PHASE0_ROWS = 1024;  // first phase; each next phase covers 16x more rows
+static const int64_t PHASE0_ROWS = 1024;  // first phase; each next phase covers 4x more rows
 
 static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
@@ -483,7 +483,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
         sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, s);
         sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
         r0 = r1;
-        span *= 16;
+        span *= 4;
     }
     sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, ovf, Q, k, ix->row_base, out_dist,
                           out_rows, flags, s);

@@ -10,10 +10,10 @@
 // So the corpus keeps a bf16 shadow copy in HBM and the batch runs as a bf16 GEMM (gemm_tile.h) whose
 // epilogue never stores scores: it compares each of them with a per-query threshold and appends the
 // rare survivors (64-bit key = coarse score | row) to a per-query list.  Thresholds tighten between
-// "phases" of geometrically growing row ranges (1 Ki, 16 Ki, 256 Ki, 4 Mi, ... rows): after each phase a
+// "phases" of geometrically growing row ranges (1 Ki, 4 Ki, 16 Ki, ... rows, x4 each): after each phase a
 // small kernel keeps the k' best coarse keys per query and publishes the new threshold.
 //
-// Exactness: the k' (= 64) coarse candidates of a query are re-scored in f32 in the canonical
+// Exactness: the k' (= 128) coarse candidates of a query are re-scored in f32 in the canonical
 // summation order of scan_exact.hip / oracle/sc_oracle.c, so every returned distance is bit-identical
 // to the exact path.  |coarse - exact| <= eps_q (bf16 input rounding, bound below), therefore a row that
 // is NOT a candidate has exact score >= tau_q - eps_q; if the k-th exact candidate score is strictly
@@ -21,9 +21,11 @@
 // survivor list overflowed) are flagged and re-run through the exact scan by the host code.
 //
 // Roofline: MFMA bf16; algorithmic FLOPs = 2 * rows * ld * Qpad per phase launch.
+#include <cstdlib>
+
 #include "gemm_tile.h"
 
-#define KPRIME 64          // coarse candidates kept per query
+#define KPRIME 128         // coarse candidates kept per query (one re-rank thread each)
 #define SEL_THREADS 256
 
 // ------------------------------------------------------------------ bf16 shadow + max norm
@@ -128,7 +130,11 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 }
 
 // 256 x 256 tile variant (gemm_tile.h, second half): 8 waves, each 128 corpus rows x 64 queries.
-template <int METRIC>
+// Per-query thresholds / norms of the workgroup's 256 queries sit in LDS behind the pipeline buffers, and a
+// lane queues its (rare) hits in registers so that the global atomics that allocate list slots are issued
+// back to back and their latency is paid once per tile, not once per hit.
+#define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256]} in LDS
+template <int METRIC, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -138,6 +144,20 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     const int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;
     const int64_t m0 = a.row0 + (int64_t)rt * T_BM;
     const int n0 = qt * T_BN;
+    float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
+    float* q_thr = q_tf + 256;
+    float* q_qn = q_tf + 512;
+    float* x_xn = q_tf + 768;  // |x|^2 of the tile's 256 corpus rows
+    if (tid >= 256) {
+        const int64_t row = m0 + (tid - 256);
+        x_xn[tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
+    }
+    if (tid < 256) {  // visible to everyone after the main loop's barriers
+        const int q = n0 + tid;
+        q_tf[tid] = a.thr_fast[q];  // padded to Qpad and +inf-initialised
+        q_thr[tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
+        q_qn[tid] = q < a.Q ? a.qnorm[q] : 1.0f;
+    }
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -145,45 +165,80 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     gemm_tile256_mainloop<0>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+    asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG) {  // diagnostic: main loop only
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
+        if (sink == 12345.678f) a.count[0] = 1;
+        return;
+    }
 
     // acc[ni][mi][r] = <x[m0 + wm*128 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 tf[4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int q0 = n0 + wn * 64 + ni * 16 + 4 * fq;  // thr_fast is allocated padded to 256 and +inf-initialised
-        tf[ni] = *reinterpret_cast<const f32x4*>(a.thr_fast + q0);
-    }
+    for (int ni = 0; ni < 4; ++ni) tf[ni] = *reinterpret_cast<const f32x4*>(q_tf + wn * 64 + ni * 16 + 4 * fq);
+    // hits of this lane: up to 4 queued (local query index, key); a 5th and later ones are flushed directly
+    int nh = 0;
+    int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
+    uint64_t hk0 = 0, hk1 = 0, hk2 = 0, hk3 = 0;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
-        const int64_t row = m0 + wm * 128 + mi * 16 + fr;
-        if (row >= a.row1) continue;
-        const float xn = a.xnorm[row];
+        const int rl = wm * 128 + mi * 16 + fr;
+        const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int q0 = n0 + wn * 64 + ni * 16 + 4 * fq;
+            // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
+            f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dot = acc[ni][mi][r];
-                float t;
-                if (METRIC == SC_METRIC_L2) t = fmaf(-2.0f, dot, xn);
-                else if (METRIC == SC_METRIC_COSINE) t = -dot * xs;
-                else t = -dot;
-                if (t <= tf[ni][r]) {
-                    const int q = q0 + r;
-                    if (q < a.Q) {
-                        const float sc = sc_score<METRIC>(dot, xn, a.qnorm[q]);
+                if (METRIC == SC_METRIC_L2) t[r] = fmaf(-2.0f, dot, xn);
+                else if (METRIC == SC_METRIC_COSINE) t[r] = -dot * xs;
+                else t[r] = -dot;
+            }
+            const bool g = (t[0] <= tf[ni][0]) | (t[1] <= tf[ni][1]) | (t[2] <= tf[ni][2]) | (t[3] <= tf[ni][3]);
+            if (__any(g)) {
+                const int64_t row = m0 + rl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row < a.row1 && t[r] <= tf[ni][r]) {
+                        const int ql = wn * 64 + ni * 16 + 4 * fq + r;
+                        const float sc = sc_score<METRIC>(acc[ni][mi][r], xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
-                        if (v <= a.thr[q]) {
-                            const unsigned pos = atomicAdd(a.count + q, 1u);
-                            if (pos < (unsigned)a.cap) a.surv[(size_t)q * a.cap + pos] = sc_make_key<METRIC>(sc, (uint32_t)row);
+                        if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries
+                            const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
+                            if (nh == 0) { hq0 = ql; hk0 = key; }
+                            else if (nh == 1) { hq1 = ql; hk1 = key; }
+                            else if (nh == 2) { hq2 = ql; hk2 = key; }
+                            else if (nh == 3) { hq3 = ql; hk3 = key; }
+                            else {
+                                const unsigned pos = atomicAdd(a.count + n0 + ql, 1u);
+                                if (pos < (unsigned)a.cap) a.surv[(size_t)(n0 + ql) * a.cap + pos] = key;
+                            }
+                            ++nh;
                         }
                     }
                 }
             }
         }
     }
+    if (!__any(nh > 0)) return;
+    // allocate the queued hits' list slots with back-to-back atomics, then store
+    unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    if (nh > 0) p0 = atomicAdd(a.count + n0 + hq0, 1u);
+    if (nh > 1) p1 = atomicAdd(a.count + n0 + hq1, 1u);
+    if (nh > 2) p2 = atomicAdd(a.count + n0 + hq2, 1u);
+    if (nh > 3) p3 = atomicAdd(a.count + n0 + hq3, 1u);
+    if (nh > 0 && p0 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq0) * a.cap + p0] = hk0;
+    if (nh > 1 && p1 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq1) * a.cap + p1] = hk1;
+    if (nh > 2 && p2 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq2) * a.cap + p2] = hk2;
+    if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
 
 // ------------------------------------------------------------------ per-phase selection: keep the KPRIME best coarse keys
@@ -238,9 +293,9 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
 }
 
 // ------------------------------------------------------------------ exact re-rank + certificate
-// One wave per query: lane j re-scores candidate j with the canonical f32 fmaf chain.
+// One 128-thread workgroup per query: thread j re-scores candidate j with the canonical f32 fmaf chain.
 template <int METRIC>
-__global__ __launch_bounds__(64) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
+__global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
                                                           const float* __restrict__ Qp, const float* __restrict__ qnorm,
                                                           const uint64_t* __restrict__ best, const float* __restrict__ thr,
                                                           const unsigned* __restrict__ xnorm_max_bits, const int* __restrict__ overflow, int k,
@@ -355,7 +410,7 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
     if ((Qpad % T_BN) == 0 && (row0 % T_BM) == 0) {  // large batches: 256 x 256 tiles (corpus rows are padded to 256)
         a.qtiles = Qpad / T_BN;
         a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);
-        const size_t lds256 = 4 * T_TILE_BYTES;
+        const size_t lds256 = 4 * T_TILE_BYTES + 4 * 256 * 4;
         static bool attr256 = false;
         if (!attr256) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
@@ -364,6 +419,12 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
             attr256 = true;
         }
         dim3 grid256((unsigned)a.ntiles), block256(512);
+        static const bool dbg = getenv("SC_COARSE_DBG") != nullptr;  // diagnostic: time the main loop alone (results invalid)
+        if (dbg) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 1>), grid256, block256, lds256, s, a);
+            return;
+        }
         if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_L2>, grid256, block256, lds256, s, a);
         else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_COSINE>, grid256, block256, lds256, s, a);
         else hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_IP>, grid256, block256, lds256, s, a);
@@ -405,7 +466,7 @@ void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap,
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
                            const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
                            float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
-    dim3 grid((unsigned)Q), block(64);
+    dim3 grid((unsigned)Q), block(KPRIME);
     if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
     else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
     else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
