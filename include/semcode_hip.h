@@ -171,11 +171,22 @@ sc_status sc_index_search(sc_index* ix, const float* q, int32_t Q, int32_t k, in
 sc_status sc_index_search_dev(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe,
                               float* out_dist_dev, int64_t* out_rows_dev);
 
+/* Replaces Collection.create_index(IVF_FLAT, nlist) + load() (milvus_store.py:76-84) for an index created with
+ * SC_INDEX_IVF_FLAT: deterministic k-means (niter Lloyd iterations on <= 256*nlist sampled rows), assignment of
+ * every row to its nearest centroid, list-major re-ordering of the corpus in HBM.  Until it is called (and again
+ * after any add / overwrite, which drop the lists) an IVF_FLAT index answers with the exhaustive scan.  After it,
+ * searches with Q * nprobe < nlist probe only the nprobe nearest lists (approximate, like the reference);
+ * larger batches keep using the exhaustive paths, whose results are a superset in quality. */
+sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed);
+/* nlist actually trained (0 = untrained), centroids [nlist, dim] and list sizes [nlist] (either may be NULL). */
+sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* centroids, int64_t* list_sizes);
+
 /* Search path selection.  mode 0 (default): exact f32 scan for <= 16 queries, bf16-MFMA coarse scan +
  * exact f32 re-rank + certificate (uncertified queries re-run exactly) for larger batches with
- * k <= 32 -- both return identical results; 1: exact scan only; 2: batched path whenever supported. */
+ * k <= 64 -- both return identical results; 1: exact scan only; 2: batched path whenever supported;
+ * 3: IVF probe whenever the index is trained (any batch size; used to measure recall). */
 sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode);
-/* After a search: which path ran (1 exact, 2 batched) and how many queries the batched path had to
+/* After a search: which path ran (1 exact, 2 batched, 3 ivf probe) and how many queries the batched path had to
  * re-run through the exact scan because their certificate failed. */
 sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified);
 

@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         h.sc_oracle_threads.restype = C.c_int32
         h.sc_oracle_synth_rows.restype = None
         h.sc_oracle_synth_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64]
+        h.sc_oracle_centroid_mean.restype = None
+        h.sc_oracle_centroid_mean.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         h.sc_oracle_set_threads.restype = None
         h.sc_oracle_set_threads.argtypes = [C.c_int32]
         # never more OpenMP threads than CPUs this process may run on (cgroup-limited GPU boxes)

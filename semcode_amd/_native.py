@@ -76,6 +76,8 @@ SIGNATURES = {
     "sc_index_fill_synthetic": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
     "sc_index_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_search_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_index_train": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
+    "sc_index_ivf_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_topk_merge_host": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -241,14 +243,28 @@ class Index:
                                      dist.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p)))
         return dist, rows
 
+    def train(self, niter: int = 10, seed: int = 0) -> None:
+        """IVF_FLAT: k-means + list build (sc_index_train)."""
+        _check(lib().sc_index_train(self.handle, int(niter), int(seed)))
+
+    def ivf_info(self) -> dict:
+        n = C.c_int32()
+        _check(lib().sc_index_ivf_info(self.handle, C.byref(n), None, None))
+        if n.value == 0:
+            return {"nlist": 0}
+        cent = np.empty((n.value, self.dim), dtype=np.float32)
+        sizes = np.empty((n.value,), dtype=np.int64)
+        _check(lib().sc_index_ivf_info(self.handle, C.byref(n), cent.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p)))
+        return {"nlist": n.value, "centroids": cent, "list_sizes": sizes}
+
     def set_search_mode(self, mode: str) -> None:
-        """'auto' | 'exact' | 'batched' (see sc_index_set_search_mode)."""
-        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2}[mode]))
+        """'auto' | 'exact' | 'batched' | 'ivf' (see sc_index_set_search_mode)."""
+        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3}[mode]))
 
     def last_search_stats(self) -> dict:
         path, unc = C.c_int32(), C.c_int32()
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
-        return {"path": {0: "none", 1: "exact", 2: "batched"}[path.value], "uncertified": unc.value}
+        return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf"}[path.value], "uncertified": unc.value}
 
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
         """Device-pointer variant (asynchronous on the runtime's stream)."""

@@ -129,8 +129,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[ni][2 * p + h] + bias4[ni];
                 if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                    const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                    v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                 }
                 *reinterpret_cast<f32x4*>(stg + (h * 16 + fr) * STG_ROW + (ni * 16 + 4 * fq) * 4) = v;
             }

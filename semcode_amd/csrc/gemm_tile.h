@@ -35,6 +35,24 @@ static __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
 }
 
+// two GELUs at once with packed f32 math (v_pk_fma_f32 / v_pk_mul_f32); used in GEMM epilogues, where no MFMA competes
+static __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 den = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 p = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 zz = z * z * -1.44269504088896340736f;
+    const f32x2 ex = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+    const f32x2 e = p * t * ex;                       // 1 - erf(z)
+    const f32x2 h = x * 0.5f;                         // gelu = h * (1 + sign(x) * (1 - e)) = h + |h| * (1 - e) ... by sign
+    const f32x2 ah = ax * 0.5f;
+    return h + (ah - ah * e);                         // x>=0: h + h(1-e) ; x<0: h - |h|... = h + |h|(1-e)  (since h = -|h|)
+}
+
 static __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 static __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     // round to nearest even; NaN stays NaN

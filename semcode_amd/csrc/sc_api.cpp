@@ -215,6 +215,11 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->xnorm_max);
     hipFree(ix->bscratch);
     hipFree(ix->fb);
+    hipFree(ix->perm);
+    hipFree(ix->inv);
+    hipFree(ix->list_off);
+    hipFree(ix->ivf_scratch);
+    if (ix->quant) sc_index_destroy(ix->quant);
     delete ix;
     return SC_OK;
 }
@@ -229,7 +234,7 @@ extern "C" sc_status sc_index_info(sc_index* ix, int64_t* rows, int32_t* dim, in
 }
 
 // grow a device scratch buffer (contents not preserved)
-static sc_status grow(sc_index* ix, void** p, size_t* cap, size_t need) {
+sc_status sc_grow(sc_index* ix, void** p, size_t* cap, size_t need) {
     if (need <= *cap) return SC_OK;
     SC_HIP(hipStreamSynchronize(ix->rt->stream));
     if (*p) hipFree(*p);
@@ -283,13 +288,15 @@ extern "C" sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n) {
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
     if (ix->n + n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "sc_index_add: more than 2^32 rows per shard");
-    sc_status st = ensure_rows(ix, ix->n + n, false);
+    sc_status st = sc_ivf_untrain_locked(ix);  // new rows belong to no list: back to insertion order until retrained
+    if (st) return st;
+    st = ensure_rows(ix, ix->n + n, false);
     if (st) return st;
     const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4));
     hipStream_t s = ix->rt->stream;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
-        st = grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
+        st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
         if (st) return st;
         SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
         sc_launch_ingest_rows((const float*)ix->stage, nullptr, ix->n + off, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
@@ -308,12 +315,16 @@ extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const i
     SC_HIP(hipSetDevice(ix->rt->device));
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= ix->n) return sc_fail(SC_ERR_INVALID, "sc_index_overwrite: row %lld out of range [0,%lld)", (long long)rows[i], (long long)ix->n);
+    {
+        sc_status ust = sc_ivf_untrain_locked(ix);
+        if (ust) return ust;
+    }
     const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4 + 8));
     hipStream_t s = ix->rt->stream;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
         const size_t vbytes = ((size_t)m * ix->dim * 4 + 15) & ~(size_t)15;
-        sc_status st = grow(ix, (void**)&ix->stage, &ix->stage_cap, vbytes + (size_t)m * 8);
+        sc_status st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, vbytes + (size_t)m * 8);
         if (st) return st;
         int64_t* drows = (int64_t*)((char*)ix->stage + vbytes);
         SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
@@ -337,9 +348,19 @@ extern "C" sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, f
     hipStream_t s = ix->rt->stream;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
-        sc_status st = grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
+        sc_status st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
         if (st) return st;
-        sc_launch_gather_rows(ix->X, ix->ld, first + off, m, ix->dim, (float*)ix->stage, s);
+        if (ix->trained) {  // list-major storage: fetch row ids first+off .. through the inverse permutation
+            std::vector<int64_t> pos((size_t)m);
+            for (int64_t i = 0; i < m; ++i) pos[(size_t)i] = ix->inv_h[(size_t)(first + off + i)];
+            st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, (size_t)m * 8);
+            if (st) return st;
+            SC_HIP(hipMemcpyAsync(ix->ivf_scratch, pos.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
+            sc_launch_rows_to_sample(ix->X, ix->ld, ix->dim, (const int64_t*)ix->ivf_scratch, m, (float*)ix->stage, s);
+            SC_HIP(hipStreamSynchronize(s));  // pos goes out of scope
+        } else {
+            sc_launch_gather_rows(ix->X, ix->ld, first + off, m, ix->dim, (float*)ix->stage, s);
+        }
         SC_HIP(hipGetLastError());
         SC_HIP(hipMemcpyAsync(out + off * ix->dim, ix->stage, (size_t)m * ix->dim * 4, hipMemcpyDeviceToHost, s));
         SC_HIP(hipStreamSynchronize(s));
@@ -352,6 +373,10 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
     if (n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    {
+        sc_status ust = sc_ivf_untrain_locked(ix);
+        if (ust) return ust;
+    }
     ix->n = 0;  // nothing to preserve
     sc_status st = ensure_rows(ix, n, true);
     if (st) return st;
@@ -372,18 +397,18 @@ static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q
     ScanPlan plan;
     if (!sc_scan_exact_plan(ix->ld, Q, k, rt->cus, &plan))
         return sc_fail(SC_ERR_UNSUPPORTED, "search: k=%d (1..1024) / dim=%d not supported by the exact scan", k, ix->dim);
-    sc_status st = grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
+    sc_status st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
     if (st) return st;
-    st = grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
-    st = grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>(plan.partial_bytes, 16));
+    st = sc_grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>(plan.partial_bytes, 16));
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ix->ld, ix->qnorm, s);
     int lists = 0;
     if (ix->n > 0) {
         hipEvent_t e0, e1;
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-        sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, Q, k, plan, ix->partial, s);
+        sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, Q, k, plan, ix->partial, ix->perm, nullptr, nullptr, 0, s);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         lists = plan.lists;
     }
@@ -450,9 +475,9 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     const int Qpad = Q > 128 ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches
     sc_status st = ensure_shadow(ix);
     if (st) return st;
-    st = grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
+    st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
     if (st) return st;
-    st = grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
     // scratch layout
     size_t off = 0;
@@ -460,7 +485,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     const size_t o_qb = carve((size_t)Qpad * ld * 2), o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4),
                  o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8),
                  o_surv = carve((size_t)Q * BATCH_CAP * 8);
-    st = grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
+    st = sc_grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
     if (st) return st;
     char* b = (char*)ix->bscratch;
     void* Qb = b + o_qb;
@@ -485,8 +510,8 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
         r0 = r1;
         span *= 4;
     }
-    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, ovf, Q, k, ix->row_base, out_dist,
-                          out_rows, flags, s);
+    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, ovf, Q, k, ix->row_base, ix->perm,
+                          out_dist, out_rows, flags, s);
     SC_HIP(hipGetLastError());
     // uncertified queries (rare): redo them with the exact scan
     std::vector<int> hflags(Q);
@@ -499,7 +524,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     if (!redo.empty()) {
         const int R = (int)redo.size();
         const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
-        st = grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
+        st = sc_grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
         if (st) return st;
         float* fq = (float*)ix->fb;
         float* fd = (float*)((char*)ix->fb + qb);
@@ -517,15 +542,24 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     return SC_OK;
 }
 
-static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
-                                   int64_t* out_rows) {
+sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
     ix->last_uncertified = 0;
     if (batched_applicable(ix, Q, k)) return search_batched_locked(ix, q_dev, Q, k, out_dist, out_rows);
-    return search_exact_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    return search_exact_locked(ix, q_dev, Q, k, 0, out_dist, out_rows);
+}
+
+static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+                                   int64_t* out_rows) {
+    ix->last_probed_lists = 0;
+    if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);
+}
+sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows) {
+    return search_dev_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
 }
 
 extern "C" sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode) {
-    if (!ix || mode < 0 || mode > 2) return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact) or 2 (batched)");
+    if (!ix || mode < 0 || mode > 3) return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact), 2 (batched) or 3 (ivf probe)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->search_mode = mode;
     return SC_OK;
@@ -565,7 +599,7 @@ extern "C" sc_status sc_index_search(sc_index* ix, const float* q, int32_t Q, in
     const size_t qb = ((size_t)Q * ix->dim * 4 + 15) & ~(size_t)15;
     const size_t db = ((size_t)Q * k * 4 + 15) & ~(size_t)15;
     const size_t rb = (size_t)Q * k * 8;
-    st = grow(ix, (void**)&ix->io, &ix->io_cap, qb + db + rb);
+    st = sc_grow(ix, (void**)&ix->io, &ix->io_cap, qb + db + rb);
     if (st) return st;
     float* dq = (float*)ix->io;
     float* dd = (float*)((char*)ix->io + qb);

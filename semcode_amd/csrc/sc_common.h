@@ -74,10 +74,12 @@ struct ScanPlan {
     size_t partial_bytes;
 };
 // returns false when (ld, k) cannot be served by the exact kernel
-bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p);
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt = 0, int nprobe = 0);
 // X [n, ld], xnorm [n]; Qp [Q, ld] zero padded, qnorm [Q]; partial: plan.partial_bytes
+// perm: stored position -> reported row (NULL = identity); seg_*: IVF probe ranges per query (NULL = all rows)
 void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp,
-                          const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, hipStream_t s);
+                          const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm,
+                          const int* seg_base, const int64_t* seg_rows, int nprobe, hipStream_t s);
 // partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k,
                           int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
@@ -95,4 +97,12 @@ void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap,
                            float* thr_fast, int* overflow, int Q, hipStream_t s);
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
                            const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
-                           float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);
+                           const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);
+
+// ivf.hip
+void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,
+                        hipStream_t s);
+void sc_launch_centroid_mean(const float* X, int ld, int dim, const int64_t* members, const int64_t* member_off, int nlist, float* C_tight,
+                             const float* C_old, int ldc_old, hipStream_t s);
+void sc_launch_permute_rows(const float* X, const float* xnorm, const uint32_t* perm, int64_t n, int ld, float* Xo, float* xnorm_o, hipStream_t s);
+void sc_launch_rows_to_sample(const float* X, int ld, int dim, const int64_t* rows, int64_t n, float* out_tight, hipStream_t s);

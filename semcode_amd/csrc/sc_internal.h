@@ -58,8 +58,26 @@ struct sc_index {
     unsigned* xnorm_max = nullptr;                // device: bits of max |x|^2
     void* bscratch = nullptr; size_t bscratch_cap = 0;
     void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results)
-    int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported
-    int last_path = 0;                            // 1 exact, 2 batched
+    // IVF_FLAT (after sc_index_train): X / xnorm are stored list-major
+    sc_index* quant = nullptr;                    // flat index over the nlist centroids (coarse quantizer)
+    uint32_t* perm = nullptr;                     // device [n]: stored position -> row id (insertion order)
+    uint32_t* inv = nullptr;                      // device [n]: row id -> stored position
+    int64_t* list_off = nullptr;                  // device [nlist + 1]
+    std::vector<uint32_t> inv_h;                  // host copy of inv (get_rows / overwrite)
+    std::vector<int64_t> list_off_h;
+    int nlist_trained = 0;
+    void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
+    int last_probed_lists = 0;
+    int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported, 3 IVF probe whenever trained
+    int last_path = 0;                            // 1 exact, 2 batched, 3 ivf probe
     int last_uncertified = 0;
     std::mutex mu;
 };
+
+// sc_api.cpp internals used by sc_ivf.cpp (caller holds ix->mu)
+sc_status sc_grow(sc_index* ix, void** p, size_t* cap, size_t need);
+sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
+sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows);
+sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
+sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
+bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe);

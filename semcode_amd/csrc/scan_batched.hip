@@ -299,8 +299,8 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
                                                           const float* __restrict__ Qp, const float* __restrict__ qnorm,
                                                           const uint64_t* __restrict__ best, const float* __restrict__ thr,
                                                           const unsigned* __restrict__ xnorm_max_bits, const int* __restrict__ overflow, int k,
-                                                          int64_t row_base, float* __restrict__ out_dist, int64_t* __restrict__ out_rows,
-                                                          int* __restrict__ flags) {
+                                                          int64_t row_base, const uint32_t* __restrict__ perm, float* __restrict__ out_dist,
+                                                          int64_t* __restrict__ out_rows, int* __restrict__ flags) {
     __shared__ uint64_t keys[KPRIME];
     const int q = blockIdx.x, lane = threadIdx.x;
     const uint64_t ck = best[(size_t)q * KPRIME + lane];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc = fmaf(xa[g][c], qa[g][c], acc);
         }
-        ek = sc_make_key<METRIC>(sc_score<METRIC>(acc, xnorm[row], qnorm[q]), row);
+        ek = sc_make_key<METRIC>(sc_score<METRIC>(acc, xnorm[row], qnorm[q]), perm ? perm[row] : row);  // ties: reported row id
     }
     keys[lane] = ek;
     __syncthreads();
@@ -465,9 +465,9 @@ void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap,
 
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
                            const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
-                           float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
+                           const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
     dim3 grid((unsigned)Q), block(KPRIME);
-    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
-    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
-    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, out_dist, out_rows, flags);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
+    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
 }

@@ -48,12 +48,20 @@ struct ScanArgs {
     int cap;
     int tiles_per_wg;
     uint64_t* partial;
+    // optional: stored position -> reported row id (list-major IVF storage); NULL = identity
+    const uint32_t* perm;
+    // optional segment mode (IVF probe, qt == 1, blockIdx.y = query): the query scans nprobe row ranges
+    // seg_rows[q][j] = {first, end}, whose 16-row tiles are numbered consecutively; seg_base[q][j] = first
+    // tile ordinal of range j, seg_base[q][nprobe] = total tiles.
+    const int* seg_base;
+    const int64_t* seg_rows;
+    int nprobe;
 };
 
 struct ScanLds {
-    unsigned ring, norms, qs, qn, thr, cnt, cand, tmp, total;
+    unsigned ring, norms, qs, qn, thr, cnt, cand, tmp, seg, total;
 };
-__host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int cap) {
+__host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int cap, int nprobe = 0) {
     ScanLds L;
     unsigned o = 0;
     L.ring = o; o += SCAN_WAVES * SCAN_NSTAGE * SCAN_STAGE_BYTES;
@@ -64,6 +72,7 @@ __host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int ca
     L.cnt = o; o += SCAN_WAVES * 16 * 4;
     L.cand = o; o += (unsigned)SCAN_WAVES * (unsigned)qt * (unsigned)cap * 8u;
     L.tmp = o; o += (unsigned)SCAN_WAVES * (unsigned)cap * 8u;
+    L.seg = o; o += nprobe ? (((unsigned)(nprobe + 1) * 4u + 15u) & ~15u) + (unsigned)nprobe * 16u : 0u;
     L.total = o;
     return L;
 }
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15;  // A row / B column (query slot)
     const int g = lane >> 4;    // k-group
-    const ScanLds L = scan_lds_layout(a.ld, a.qt, a.cap);
+    const ScanLds L = scan_lds_layout(a.ld, a.qt, a.cap, a.seg_base ? a.nprobe : 0);
     const int ld = a.ld;
     const int spt = ld >> 6;  // stages per tile
     const int grp = blockIdx.y;
@@ -118,13 +127,23 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
             reinterpret_cast<uint64_t*>(smem + L.thr)[tid] = SC_KEY_MAX;
             reinterpret_cast<unsigned*>(smem + L.cnt)[tid] = 0u;
         }
+        if (a.seg_base) {
+            int* sb = reinterpret_cast<int*>(smem + L.seg);
+            int64_t* sr = reinterpret_cast<int64_t*>(smem + L.seg + (((unsigned)(a.nprobe + 1) * 4u + 15u) & ~15u));
+            for (int j = tid; j <= a.nprobe; j += 256) sb[j] = a.seg_base[(size_t)q0 * (a.nprobe + 1) + j];
+            for (int j = tid; j < 2 * a.nprobe; j += 256) sr[j] = a.seg_rows[(size_t)q0 * 2 * a.nprobe + j];
+        }
     }
     __syncthreads();
+    const int* seg_b = reinterpret_cast<const int*>(smem + L.seg);
+    const int64_t* seg_r = reinterpret_cast<const int64_t*>(smem + L.seg + (((unsigned)(a.nprobe + 1) * 4u + 15u) & ~15u));
+    const bool segmode = a.seg_base != nullptr;
 
     // ---- this wave's tiles: wg range [t0, t1), wave takes t0 + w, t0 + w + 4, ...
-    const int64_t total_tiles = (a.n + 15) >> 4;
-    const int64_t t0 = (int64_t)blockIdx.x * a.tiles_per_wg;
-    int64_t t1 = t0 + a.tiles_per_wg;
+    const int64_t total_tiles = segmode ? (int64_t)seg_b[a.nprobe] : (a.n + 15) >> 4;
+    const int tiles_per_wg = segmode ? (int)((total_tiles + gridDim.x - 1) / gridDim.x) : a.tiles_per_wg;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wg;
+    int64_t t1 = t0 + tiles_per_wg;
     if (t1 > total_tiles) t1 = total_tiles;
     int ntiles = 0;
     if (t0 + w < t1) ntiles = (int)((t1 - (t0 + w) + SCAN_WAVES - 1) / SCAN_WAVES);
@@ -140,17 +159,30 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     const float qn_mine = reinterpret_cast<const float*>(smem + L.qn)[r16];
     const int64_t last_row = a.n - 1;
 
+    // tile ordinal -> first row and last valid row; `j` is a monotone cursor over the probe ranges
+    auto tile_span = [&](int64_t ord, int& j, int64_t& row0, int64_t& last) {
+        if (!segmode) {
+            row0 = ord << 4;
+            last = last_row;
+        } else {
+            while (j + 1 < a.nprobe && ord >= seg_b[j + 1]) ++j;
+            row0 = seg_r[2 * j] + ((ord - seg_b[j]) << 4);
+            last = seg_r[2 * j + 1] - 1;
+        }
+    };
+    int iss_j = 0, con_j = 0;
     // issue side: (tile ordinal, k-chunk) of the next stage to request
     int iss = 0, iss_tile = 0, iss_kc = 0;
     // per-lane source geometry of one LDS-DMA piece: row-in-piece = lane>>4, slot = lane&15
     const int prow = lane >> 4, pslot = lane & 15;
 
     auto issue_stage = [&]() {
-        const int64_t row0 = (t0 + w + (int64_t)iss_tile * SCAN_WAVES) << 4;
+        int64_t row0, tlast;
+        tile_span(t0 + w + (int64_t)iss_tile * SCAN_WAVES, iss_j, row0, tlast);
         const int slot = iss & (SCAN_NSTAGE - 1);
         if (iss_kc == 0) {  // tile norms first: older than the tile's data in the vmcnt queue
             int64_t rr = row0 + r16;
-            rr = rr > last_row ? last_row : rr;
+            rr = rr > tlast ? tlast : rr;
             __builtin_amdgcn_global_load_lds((gbl_vptr)(a.xnorm + rr), (lds_vptr)(nrm + (iss_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES),
                                              4, 0, 0);
         }
@@ -159,7 +191,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int r = 4 * p + prow;
             int64_t rr = row0 + r;
-            rr = rr > last_row ? last_row : rr;
+            rr = rr > tlast ? tlast : rr;
             const float* src = a.X + rr * (int64_t)ld + (iss_kc << 6) + ((pslot ^ r) << 2);
             __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(dst + p * 1024), 16, 0, 0);
         }
@@ -195,15 +227,21 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
 
         if (++con_kc == spt) {
             // ---- tile done: lane holds query r16, rows row0 + 4g + {0..3}
-            const int64_t row0 = (t0 + w + (int64_t)con_tile * SCAN_WAVES) << 4;
+            int64_t row0, tlast;
+            tile_span(t0 + w + (int64_t)con_tile * SCAN_WAVES, con_j, row0, tlast);
             const f32x4 xn = *reinterpret_cast<const f32x4*>(nrm + (con_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES + g * 16);
             const uint64_t thr = thr_w[r16];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int64_t row = row0 + 4 * g + c;
                 const float sc = sc_score<METRIC>(acc[c], xn[c], qn_mine);
-                const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
-                if (r16 < nq && row <= last_row && key < thr) {
+                uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
+                // with a permutation the low word is only known after a (rare-path) lookup: compare scores first
+                const bool cand = r16 < nq && row <= tlast && (a.perm ? (key >> 32) <= (thr >> 32) : key < thr);
+                if (cand && a.perm) {
+                    key = (key & 0xFFFFFFFF00000000ull) | a.perm[row];
+                }
+                if (cand && key < thr) {
                     // inline asm: a compiler-visible LDS write here would get an s_waitcnt vmcnt(0) in front
                     // of it (it may alias the in-flight LDS-DMA as far as hipcc knows) and drain the ring.
                     unsigned pos;
@@ -237,30 +275,33 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     }
 }
 
-bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p) {
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt, int nprobe) {
     if (ld <= 0 || (ld % SC_LD_ALIGN) != 0 || k < 1 || k > 1024 || Q < 1) return false;
     const int cap = ((k + 16 + 63) / 64) * 64;  // >= k + 16, multiple of 64
     const unsigned budget = 160 * 1024;
     int qt = Q < 16 ? Q : 16;
-    while (qt >= 1 && scan_lds_layout(ld, qt, cap).total > budget) --qt;
+    if (force_qt > 0 && force_qt < qt) qt = force_qt;
+    while (qt >= 1 && scan_lds_layout(ld, qt, cap, nprobe).total > budget) --qt;
     if (qt < 1) return false;
     p->qt = qt;
     p->groups = (Q + qt - 1) / qt;
     p->nwg = cus > 0 ? cus : 256;
     p->cap = cap;
     p->lists = p->nwg * SCAN_WAVES;
-    p->lds = scan_lds_layout(ld, qt, cap).total;
+    p->lds = scan_lds_layout(ld, qt, cap, nprobe).total;
     p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t);
     return true;
 }
 
 void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp, const float* qnorm,
-                          int Q, int k, const ScanPlan& p, uint64_t* partial, hipStream_t s) {
+                          int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm, const int* seg_base,
+                          const int64_t* seg_rows, int nprobe, hipStream_t s) {
     ScanArgs a;
     a.X = X; a.xnorm = xnorm; a.n = n; a.ld = ld; a.Qp = Qp; a.qnorm = qnorm; a.Q = Q; a.qt = p.qt; a.k = k; a.cap = p.cap;
     const int64_t tiles = (n + 15) / 16;
     a.tiles_per_wg = (int)((tiles + p.nwg - 1) / p.nwg);
     a.partial = partial;
+    a.perm = perm; a.seg_base = seg_base; a.seg_rows = seg_rows; a.nprobe = nprobe;
     dim3 grid((unsigned)p.nwg, (unsigned)p.groups), block(256);
     static bool attr_done = false;
     if (!attr_done) {

@@ -109,6 +109,7 @@ class MilvusVectorStore:
         self._paths: List[str] = []
         self._languages: List[str] = []
         self._row_of: dict[str, int] = {}
+        self._needs_train = False  # IVF_FLAT lists are (re)built lazily before a search, like Milvus' background index build
 
     # ------------------------------------------------------------------ lifecycle
     def connect(self) -> None:
@@ -166,6 +167,7 @@ class MilvusVectorStore:
             inserted += len(batch)
             if progress:
                 progress(inserted, total)
+        self._needs_train = True
 
     def _upsert_batch(self, batch: Sequence[EmbeddingPayload]) -> None:
         vectors = np.asarray([p.vector for p in batch], dtype=np.float32)
@@ -223,7 +225,23 @@ class MilvusVectorStore:
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"query dimension mismatch: collection dim={self.dim}, got shape {q.shape}")
         with self._lock:
+            self._maybe_train()
             return self._collection.search(q, k=int(top_k), nprobe=self.nprobe)
+
+    def build_index(self, niter: int = 10) -> None:
+        """(Re)build the IVF_FLAT lists now (create_index + load of the reference, milvus_store.py:76-84)."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        with self._lock:
+            if self.index_type == "IVF_FLAT" and hasattr(self._collection, "train") and len(self._ids) > 0:
+                self._collection.train(niter=niter)
+            self._needs_train = False
+
+    def _maybe_train(self) -> None:
+        # faiss' rule of thumb: at least 39 points per centroid, otherwise the exhaustive scan is used (exact results)
+        if self._needs_train and self.index_type == "IVF_FLAT" and hasattr(self._collection, "train") and len(self._ids) >= 39 * self.nlist:
+            self._collection.train(niter=10)
+        self._needs_train = False
 
     def hits_for(self, dist: np.ndarray, rows: np.ndarray) -> SearchResult:
         """Materialise pymilvus-shaped results for a search_batch() output."""

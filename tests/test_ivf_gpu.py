@@ -1,0 +1,111 @@
+"""GPU: IVF_FLAT build (deterministic k-means + list-major re-ordering) and probe search against the CPU
+restatement (oracle/ivf_oracle.py): centroids bit-exact, identical lists, identical results; recall vs brute force."""
+import numpy as np
+import pytest
+
+from oracle import sc_oracle as orc
+from oracle.ivf_oracle import IvfOracle
+from semcode_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def clustered(n, d, ncl, seed, spread=0.35):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((ncl, d)).astype(np.float32)
+    lab = rng.integers(0, ncl, size=n)
+    return (centers[lab] + spread * rng.standard_normal((n, d))).astype(np.float32), centers
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+def test_build_and_probe_match_oracle(rt, metric):
+    X, centers = clustered(20_000, 64, 40, seed=1)
+    rng = np.random.default_rng(2)
+    Q = (centers[rng.integers(0, 40, size=5)] + 0.3 * rng.standard_normal((5, 64))).astype(np.float32)
+    ix = _native.Index(rt, 64, metric=metric, kind="IVF_FLAT", nlist=32)
+    ix.add(X)
+    # before training: exhaustive scan
+    d0, r0 = ix.search(Q, k=10, nprobe=4)
+    od, orow = orc.search(X, Q, 10, metric)
+    assert np.array_equal(r0, orow) and np.array_equal(bits(d0), bits(od)) and ix.last_search_stats()["path"] == "exact"
+    ix.train(niter=6)
+    ref = IvfOracle(X, metric, nlist=32, niter=6)
+    info = ix.ivf_info()
+    assert info["nlist"] == 32
+    assert np.array_equal(bits(info["centroids"]), bits(ref.centroids)), "centroids differ from the restatement"
+    assert info["list_sizes"].tolist() == [len(l) for l in ref.lists]
+    assert np.array_equal(ix.get_rows(0, 20_000), X)  # row ids stay insertion-ordered although storage is list-major
+    d, r = ix.search(Q, k=10, nprobe=4)
+    assert ix.last_search_stats()["path"] == "ivf"
+    rd, rr = ref.search(Q, 10, 4)
+    assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
+    # more queries than lists/nprobe: automatic switch to the exhaustive paths (exact results)
+    Qb = (centers[rng.integers(0, 40, size=64)] + 0.3 * rng.standard_normal((64, 64))).astype(np.float32)
+    d, r = ix.search(Qb, k=10, nprobe=4)
+    assert ix.last_search_stats()["path"] in ("exact", "batched")
+    od, orow = orc.search(X, Qb, 10, metric)
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.close()
+
+
+def test_recall_and_forced_probe_on_larger_set(rt):
+    X, centers = clustered(300_000, 128, 500, seed=3)
+    rng = np.random.default_rng(4)
+    Q = (centers[rng.integers(0, 500, size=200)] + 0.35 * rng.standard_normal((200, 128))).astype(np.float32)
+    ix = _native.Index(rt, 128, metric="L2", kind="IVF_FLAT", nlist=256)
+    ix.add(X)
+    ix.train(niter=8)
+    ix.set_search_mode("exact")
+    de, re_ = ix.search(Q, k=10)
+    ix.set_search_mode("ivf")
+    for nprobe, floor in ((1, 0.3), (8, 0.85), (32, 0.97)):
+        d, r = ix.search(Q, k=10, nprobe=nprobe)
+        assert ix.last_search_stats()["path"] == "ivf"
+        recall = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(r.tolist(), re_.tolist())])
+        assert recall >= floor, (nprobe, recall)
+        # whatever is returned carries exact distances, best first, and real row ids
+        assert (np.diff(d, axis=1) >= 0).all()
+        qi = 7
+        od, _ = orc.search(X[r[qi]], Q[qi:qi + 1], 10, "L2")
+        assert np.array_equal(bits(od[0]), bits(d[qi]))
+    ix.close()
+
+
+def test_mutation_after_training_falls_back_to_exhaustive(rt):
+    X, _ = clustered(5000, 64, 10, seed=5)
+    Q = X[[3, 4000]] + 0.01
+    ix = _native.Index(rt, 64, metric="IP", kind="IVF_FLAT", nlist=16)
+    ix.add(X)
+    ix.train(niter=4)
+    assert ix.ivf_info()["nlist"] == 16
+    extra = (3.0 * Q).astype(np.float32)
+    ix.add(extra)  # lists dropped, insertion order restored
+    assert ix.ivf_info()["nlist"] == 0
+    X2 = np.concatenate([X, extra])
+    assert np.array_equal(ix.get_rows(0, len(X2)), X2)
+    d, r = ix.search(Q, k=5, nprobe=2)
+    od, orow = orc.search(X2, Q, 5, "IP")
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.train(niter=4)  # can be retrained
+    d, r = ix.search(Q[:1], k=1, nprobe=4)
+    assert ix.last_search_stats()["path"] == "ivf" and r[0, 0] == 5000
+    ix.close()
+
+
+def test_train_errors(rt):
+    flat = _native.Index(rt, 64, metric="L2", kind="FLAT")
+    flat.add(np.zeros((10, 64), np.float32))
+    with pytest.raises(_native.ScError):
+        flat.train()
+    empty = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=8)
+    with pytest.raises(_native.ScError):
+        empty.train()
+    tiny = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=128)
+    tiny.add(np.random.default_rng(0).standard_normal((20, 64)).astype(np.float32))
+    tiny.train(niter=2)  # nlist clamps to the row count
+    assert tiny.ivf_info()["nlist"] == 20
+    flat.close(); empty.close(); tiny.close()
