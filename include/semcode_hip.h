@@ -161,6 +161,12 @@ sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, float* out);
 /* Resize to n rows and fill them on device with sc_synth_fill_dev(seed, first_row). */
 sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t seed, int64_t first_row);
 
+/* Clustered synthetic corpus (IVF recall benchmarks): row = centre[hash(row) % nclusters] + spread * noise, all
+ * from the same integer-hash generator. */
+sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, uint64_t seed, int64_t first_row, int32_t nclusters, float spread);
+/* Free the rebuildable device buffers of an index (bf16 shadow, search scratch). */
+sc_status sc_index_release_scratch(sc_index* ix);
+
 /* Replaces Collection.search(data=[vector], param={metric, nprobe}, limit=top_k)
  * (milvus_store.py:141-147), batched: q [Q,dim] host, out_dist [Q,k] f32, out_rows [Q,k] i64
  * (global ids, best first; ties broken by lower row id; missing hits = -1 / +inf-or--inf).

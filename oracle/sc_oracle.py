@@ -106,6 +106,26 @@ def synth_rows(rows_idx, dim: int, seed: int) -> np.ndarray:
     return out
 
 
+M64 = (1 << 64) - 1
+
+
+def _mix64(z: int) -> int:
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def synth_clustered(rows: int, dim: int, seed: int, nclusters: int, spread: float, first_row: int = 0) -> np.ndarray:
+    """Clustered corpus of sc_index_fill_synthetic_clustered: centre[hash(row) % nclusters] + spread * noise (one fmaf)."""
+    cseed = seed ^ 0xC1057E25
+    ckey = _mix64((cseed + 0x9E3779B97F4A7C15) & M64)
+    cl = np.array([_mix64(ckey ^ (((first_row + r) * 0x9E3779B97F4A7C15) & M64)) % nclusters for r in range(rows)], dtype=np.int64)
+    noise = synth(rows, dim, seed, first_row=first_row)
+    centres = synth_rows(cl, dim, cseed)
+    # fmaf(spread, noise, centre): one rounding -> do it in float64 (exact product of two f32 fits) and round once
+    return (np.float64(np.float32(spread)) * noise.astype(np.float64) + centres.astype(np.float64)).astype(np.float32)
+
+
 def sqnorm(x: np.ndarray) -> float:
     x = np.ascontiguousarray(x, dtype=np.float32)
     return float(lib().sc_oracle_sqnorm(x.ctypes.data_as(C.c_void_p), x.shape[0]))

@@ -9,6 +9,7 @@ reference src/semcode/services/indexer.py:57-63, src/semcode/rag/pipeline.py:95-
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import threading
 from pathlib import Path
 
@@ -74,6 +75,8 @@ SIGNATURES = {
     "sc_index_overwrite": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "sc_index_get_rows": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "sc_index_fill_synthetic": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
+    "sc_index_fill_synthetic_clustered": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_float]),
+    "sc_index_release_scratch": (C.c_int32, [C.c_void_p]),
     "sc_index_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_search_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_train": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
@@ -133,7 +136,8 @@ class Runtime:
 
     def __del__(self):  # pragma: no cover - best effort
         try:
-            self.close()
+            if not sys.is_finalizing():  # at interpreter shutdown handle order is arbitrary: leave it to process exit
+                self.close()
         except Exception:
             pass
 
@@ -193,7 +197,8 @@ class Index:
 
     def __del__(self):  # pragma: no cover
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
@@ -232,6 +237,12 @@ class Index:
 
     def fill_synthetic(self, n: int, seed: int, first_row: int = 0) -> None:
         _check(lib().sc_index_fill_synthetic(self.handle, int(n), int(seed), int(first_row)))
+
+    def fill_synthetic_clustered(self, n: int, seed: int, nclusters: int, spread: float, first_row: int = 0) -> None:
+        _check(lib().sc_index_fill_synthetic_clustered(self.handle, int(n), int(seed), int(first_row), int(nclusters), float(spread)))
+
+    def release_scratch(self) -> None:
+        _check(lib().sc_index_release_scratch(self.handle))
 
     def search(self, queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:
         """queries [Q, dim] -> (dist [Q, k] f32, rows [Q, k] i64), best first."""
@@ -305,7 +316,8 @@ class Encoder:
 
     def __del__(self):  # pragma: no cover
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 

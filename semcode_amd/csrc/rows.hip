@@ -43,6 +43,48 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(float* __restrict__ out
     }
 }
 
+// clustered variant: row r = centre(cluster(r)) + spread * noise(r); cluster(r) = hash(seed, r) % nclusters,
+// centre values and noise from the same integer-hash generator (restated by the CPU oracle's synth_clustered)
+__global__ __launch_bounds__(256) void synth_clustered_rows_kernel(float* __restrict__ out, int64_t rows, int dim, int ld, uint64_t key,
+                                                                    uint64_t ckey, int64_t first_row, int nclusters, float spread,
+                                                                    float* __restrict__ xnorm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const uint64_t gr = (uint64_t)(first_row + r);
+        const uint64_t cl = sc_mix64(ckey ^ (gr * 0x9E3779B97F4A7C15ull)) % (uint64_t)nclusters;
+        float* o = out + r * (int64_t)ld;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = (k0 + c < dim) ? fmaf(spread, sc_synth_value(key, gr, (uint32_t)(k0 + c), (uint32_t)dim),
+                                             sc_synth_value(ckey, cl, (uint32_t)(k0 + c), (uint32_t)dim))
+                                      : 0.0f;
+            *reinterpret_cast<f32x4*>(o + k0) = v;
+            p0 = fmaf(v[0], v[0], p0);
+            p1 = fmaf(v[1], v[1], p1);
+            p2 = fmaf(v[2], v[2], p2);
+            p3 = fmaf(v[3], v[3], p3);
+        }
+        if (xnorm) {
+            float s = wave_butterfly_sum((p0 + p1) + (p2 + p3));
+            if (lane == 0) xnorm[r] = s;
+        }
+    }
+}
+
+void sc_launch_synth_clustered(float* out, int64_t rows, int dim, int ld, uint64_t seed, int64_t first_row, int nclusters, float spread,
+                               float* xnorm, hipStream_t s) {
+    if (rows <= 0) return;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(synth_clustered_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, rows, dim, ld, sc_synth_key(seed),
+                       sc_synth_key(seed ^ 0xC1057E25ull), first_row, nclusters, spread, xnorm);
+}
+
 void sc_launch_synth_fill(float* out, int64_t rows, int dim, int ld, uint64_t seed, int64_t first_row, float* xnorm,
                           hipStream_t s) {
     if (rows <= 0) return;

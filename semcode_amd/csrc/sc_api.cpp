@@ -388,6 +388,40 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     return SC_OK;
 }
 
+extern "C" sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, uint64_t seed, int64_t first_row, int32_t nclusters,
+                                                       float spread) {
+    if (!ix || n < 0 || nclusters < 1) return sc_fail(SC_ERR_INVALID, "sc_index_fill_synthetic_clustered: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    if (n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    sc_status st = sc_ivf_untrain_locked(ix);
+    if (st) return st;
+    ix->n = 0;
+    st = ensure_rows(ix, n, true);
+    if (st) return st;
+    sc_launch_synth_clustered(ix->X, n, ix->dim, ix->ld, seed, first_row, nclusters, spread, ix->xnorm, ix->rt->stream);
+    SC_HIP(hipGetLastError());
+    ix->n = n;
+    ix->trained = false;
+    ix->shadow_rows = 0;
+    return SC_OK;
+}
+
+// Free everything that can be rebuilt (bf16 shadow, search scratch): for corpora close to the HBM capacity.
+extern "C" sc_status sc_index_release_scratch(sc_index* ix) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    SC_HIP(hipStreamSynchronize(ix->rt->stream));
+    hipFree(ix->Xb); ix->Xb = nullptr; ix->xb_cap = 0; ix->shadow_rows = 0;
+    hipFree(ix->bscratch); ix->bscratch = nullptr; ix->bscratch_cap = 0;
+    hipFree(ix->partial); ix->partial = nullptr; ix->partial_cap = 0;
+    hipFree(ix->stage); ix->stage = nullptr; ix->stage_cap = 0;
+    hipFree(ix->fb); ix->fb = nullptr; ix->fb_cap = 0;
+    hipFree(ix->ivf_scratch); ix->ivf_scratch = nullptr; ix->ivf_scratch_cap = 0;
+    return SC_OK;
+}
+
 // q_dev: tight [Q, dim] device; outputs device.  Caller holds ix->mu.
 static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
                                    int64_t* out_rows) {
@@ -448,7 +482,9 @@ static sc_status ensure_shadow(sc_index* ix) {
         ix->shadow_rows = 0;
     }
     if (ix->shadow_rows < ix->n) {
-        sc_launch_shadow(ix->X, ix->shadow_rows, ix->n - ix->shadow_rows, ix->ld, ix->Xb, s);
+        // xnorm_max = float bits of {max |x|^2, max |x - bf16(x)|^2, max |x - bf16(x)|^2 / |x|^2} over the rows
+        if (ix->shadow_rows == 0) SC_HIP(hipMemsetAsync(ix->xnorm_max, 0, 16, s));
+        sc_launch_shadow(ix->X, ix->xnorm, ix->shadow_rows, ix->n - ix->shadow_rows, ix->ld, ix->Xb, ix->xnorm_max + 1, s);
         if (rows_pad > ix->n)  // the last row tile reads these rows: keep them finite
             SC_HIP(hipMemsetAsync((char*)ix->Xb + (size_t)ix->n * ix->ld * 2, 0, (size_t)(rows_pad - ix->n) * ix->ld * 2, s));
         sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max, s);
@@ -482,6 +518,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     // scratch layout
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_qres = carve((size_t)Q * 4);
     const size_t o_qb = carve((size_t)Qpad * ld * 2), o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4),
                  o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8),
                  o_surv = carve((size_t)Q * BATCH_CAP * 8);
@@ -489,13 +526,14 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     if (st) return st;
     char* b = (char*)ix->bscratch;
     void* Qb = b + o_qb;
+    float* qres = (float*)(b + o_qres);
     float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
     unsigned* cnt = (unsigned*)(b + o_cnt);
     int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
     uint64_t *best = (uint64_t*)(b + o_best), *surv = (uint64_t*)(b + o_surv);
 
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, s);
+    sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, s);
     int64_t r0 = 0, span = PHASE0_ROWS;
     while (r0 < ix->n) {
@@ -510,7 +548,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
         r0 = r1;
         span *= 4;
     }
-    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, ovf, Q, k, ix->row_base, ix->perm,
+    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, qres, ovf, Q, k, ix->row_base, ix->perm,
                           out_dist, out_rows, flags, s);
     SC_HIP(hipGetLastError());
     // uncertified queries (rare): redo them with the exact scan

@@ -60,6 +60,8 @@ __host__ __device__ static inline float sc_key_score(int metric, uint64_t key) {
 
 // rows.hip: out [rows, ld] synthetic (+ optional |x|^2); tight [n, dim] -> padded rows (+ |x|^2); rows -> tight
 void sc_launch_synth_fill(float* out, int64_t rows, int dim, int ld, uint64_t seed, int64_t first_row, float* xnorm, hipStream_t s);
+void sc_launch_synth_clustered(float* out, int64_t rows, int dim, int ld, uint64_t seed, int64_t first_row, int nclusters, float spread,
+                               float* xnorm, hipStream_t s);
 void sc_launch_ingest_rows(const float* src, const int64_t* rows, int64_t first, int64_t n, int dim, float* dst, int ld,
                            float* xnorm, hipStream_t s);
 void sc_launch_gather_rows(const float* src, int ld, int64_t first, int64_t n, int dim, float* dst, hipStream_t s);
@@ -86,9 +88,9 @@ void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int l
 
 // scan_batched.hip: bf16 shadow, coarse GEMM + filter phases, selection, exact re-rank
 int sc_batched_kprime(void);
-void sc_launch_shadow(const float* X, int64_t first, int64_t n, int ld, void* Xb, hipStream_t s);
+void sc_launch_shadow(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, void* Xb, unsigned* res_bits, hipStream_t s);
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s);
-void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, hipStream_t s);
+void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s);
 void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, hipStream_t s);
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
@@ -96,8 +98,8 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
                            float* thr_fast, int* overflow, int Q, hipStream_t s);
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
-                           const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
-                           const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);
+                           const float* thr, const unsigned* xnorm_max_bits, const float* qres, const int* overflow, int Q, int k,
+                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);
 
 // ivf.hip
 void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,

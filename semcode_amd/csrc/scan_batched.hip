@@ -28,15 +28,39 @@
 #define KPRIME 128         // coarse candidates kept per query (one re-rank thread each)
 #define SEL_THREADS 256
 
-// ------------------------------------------------------------------ bf16 shadow + max norm
-__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ X, int64_t first, int64_t n, int ld, bf16_t* __restrict__ Xb) {
-    const int64_t total = n * (int64_t)(ld / 4);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(X + first * ld + i * 4);
-        u16x4 o;
+// ------------------------------------------------------------------ bf16 shadow + max norm + max rounding residual
+// One wave per row: Xb = bf16(X); res_bits = max over rows of |x - bf16(x)|^2 (the certificate's error bound uses the
+// actual rounding residual, by Cauchy-Schwarz |<x,q> - <xb,qb>| <= |x - xb| |q| + |xb| |q - qb|).
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int64_t first, int64_t n, int ld,
+                                                      bf16_t* __restrict__ Xb, unsigned* __restrict__ res_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float worst = 0.f, worst_rel = 0.f;
+    for (int64_t r = wave0; r < n; r += nwaves) {
+        const float* x = X + (first + r) * (int64_t)ld;
+        bf16_t* o = Xb + (first + r) * (int64_t)ld;
+        float res = 0.f;
+        for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0);
+            u16x4 b;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = f32_to_bf16(v[c]);
-        *reinterpret_cast<u16x4*>(Xb + first * ld + i * 4) = o;
+            for (int c = 0; c < 4; ++c) {
+                b[c] = f32_to_bf16(v[c]);
+                const float d = v[c] - bf16_to_f32(b[c]);
+                res = fmaf(d, d, res);
+            }
+            *reinterpret_cast<u16x4*>(o + k0) = b;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+        worst = fmaxf(worst, res);
+        const float xn = xnorm[first + r];
+        if (xn > 0.f) worst_rel = fmaxf(worst_rel, res / xn);
+    }
+    if (lane == 0 && worst > 0.f) {
+        atomicMax(res_bits, __builtin_bit_cast(unsigned, worst * 1.0001f));          // max |x - xb|^2
+        atomicMax(res_bits + 1, __builtin_bit_cast(unsigned, worst_rel * 1.0001f));  // max |x - xb|^2 / |x|^2
     }
 }
 __global__ __launch_bounds__(256) void norm_max_kernel(const float* __restrict__ xnorm, int64_t n, unsigned* __restrict__ out_bits) {
@@ -46,11 +70,29 @@ __global__ __launch_bounds__(256) void norm_max_kernel(const float* __restrict__
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bits
 }
-// f32 padded queries [Q, ld] -> bf16 [Qpad, ld] (rows >= Q zero)
-__global__ __launch_bounds__(256) void query_bf16_kernel(const float* __restrict__ Qp, int Q, int Qpad, int ld, bf16_t* __restrict__ Qb) {
-    const int64_t total = (int64_t)Qpad * ld;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-        Qb[i] = (i / ld) < Q ? f32_to_bf16(Qp[i]) : (bf16_t)0;
+// f32 padded queries [Q, ld] -> bf16 [Qpad, ld] (rows >= Q zero) and qres[q] = |q - bf16(q)|^2 ; one wave per query row
+__global__ __launch_bounds__(256) void query_bf16_kernel(const float* __restrict__ Qp, int Q, int Qpad, int ld, bf16_t* __restrict__ Qb,
+                                                          float* __restrict__ qres) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Qpad) return;
+    float res = 0.f;
+    for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+        u16x4 b = {0, 0, 0, 0};
+        if (q < Q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Qp + (size_t)q * ld + k0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                b[c] = f32_to_bf16(v[c]);
+                const float d = v[c] - bf16_to_f32(b[c]);
+                res = fmaf(d, d, res);
+            }
+        }
+        *reinterpret_cast<u16x4*>(Qb + (size_t)q * ld + k0) = b;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+    if (lane == 0 && q < Q) qres[q] = res * 1.0001f;
 }
 
 // ------------------------------------------------------------------ coarse GEMM + filter
@@ -298,7 +340,8 @@ template <int METRIC>
 __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
                                                           const float* __restrict__ Qp, const float* __restrict__ qnorm,
                                                           const uint64_t* __restrict__ best, const float* __restrict__ thr,
-                                                          const unsigned* __restrict__ xnorm_max_bits, const int* __restrict__ overflow, int k,
+                                                          const unsigned* __restrict__ xnorm_max_bits, const float* __restrict__ qres,
+                                                          const int* __restrict__ overflow, int k,
                                                           int64_t row_base, const uint32_t* __restrict__ perm, float* __restrict__ out_dist,
                                                           int64_t* __restrict__ out_rows, int* __restrict__ flags) {
     __shared__ uint64_t keys[KPRIME];
@@ -349,14 +392,19 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
     if (lane == 0) {
         int bad = overflow[q];
         if (have == KPRIME) {  // otherwise every row of the corpus is a candidate: nothing can be missing
-            const float u = 0.00390625f;                       // bf16 unit roundoff 2^-8
-            const float C = 2.0f * u + u * u + (float)ld * 1.2e-7f;  // input rounding + f32 accumulation
-            const float xmax = sqrtf(__builtin_bit_cast(float, *xnorm_max_bits));
+            // |coarse dot - exact dot| <= |x - xb| |q| + |xb| |q - qb| + f32 accumulation noise  (Cauchy-Schwarz on the
+            // actual rounding residuals; xnorm_max_bits = {max |x|^2, max |x - xb|^2} over the corpus)
+            const float xmax = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[0]));
+            const float xres = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[1]));
             const float qn = sqrtf(qnorm[q]);
+            const float ddot = xres * qn + (xmax + xres) * sqrtf(qres[q]) + (float)ld * 1.2e-7f * (xmax + xres) * qn;
             float eps;
-            if (METRIC == SC_METRIC_L2) eps = 2.0f * C * xmax * qn;
-            else if (METRIC == SC_METRIC_COSINE) eps = C;
-            else eps = C * xmax * qn;
+            if (METRIC == SC_METRIC_L2) eps = 2.0f * ddot;
+            else if (METRIC == SC_METRIC_COSINE) {  // relative form: |x - xb|/|x| + (1 + .)|q - qb|/|q|
+                const float relx = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[2]));
+                eps = relx + (1.0f + relx) * (sqrtf(qres[q]) / fmaxf(qn, 1e-30f)) + (float)ld * 1.2e-7f * (1.0f + relx);
+            }
+            else eps = ddot;
             eps = eps * 1.01f + 1e-6f;
             const int kk = k < have ? k : have;
             const float sc = sc_key_score(METRIC, keys[kk - 1]);
@@ -380,23 +428,20 @@ void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t
     const int n = Q * KPRIME > qpad ? Q * KPRIME : qpad;
     hipLaunchKernelGGL(scan_batched_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, thr, thr_fast, qpad, best, count, overflow, Q);
 }
-void sc_launch_shadow(const float* X, int64_t first, int64_t n, int ld, void* Xb, hipStream_t s) {
+void sc_launch_shadow(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, void* Xb, unsigned* res_bits, hipStream_t s) {
     if (n <= 0) return;
-    int64_t blocks = (n * (ld / 4) + 255) / 256;
+    int64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, first, n, ld, (bf16_t*)Xb);
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, xnorm, first, n, ld, (bf16_t*)Xb, res_bits);
 }
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s) {
-    hipMemsetAsync(out_bits, 0, 4, s);
     if (n <= 0) return;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(norm_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xnorm, n, out_bits);
 }
-void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, hipStream_t s) {
-    int64_t blocks = ((int64_t)Qpad * ld + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(query_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Qp, Q, Qpad, ld, (bf16_t*)Qb);
+void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s) {
+    hipLaunchKernelGGL(query_bf16_kernel, dim3((unsigned)((Qpad + 3) / 4)), dim3(256), 0, s, Qp, Q, Qpad, ld, (bf16_t*)Qb, qres);
 }
 
 int sc_batched_kprime(void) { return KPRIME; }
@@ -464,10 +509,10 @@ void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap,
 }
 
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
-                           const float* thr, const unsigned* xnorm_max_bits, const int* overflow, int Q, int k, int64_t row_base,
-                           const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
+                           const float* thr, const unsigned* xnorm_max_bits, const float* qres, const int* overflow, int Q, int k,
+                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
     dim3 grid((unsigned)Q), block(KPRIME);
-    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
-    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
-    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, overflow, k, row_base, perm, out_dist, out_rows, flags);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
+    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
 }

@@ -109,3 +109,12 @@ def test_train_errors(rt):
     tiny.train(niter=2)  # nlist clamps to the row count
     assert tiny.ivf_info()["nlist"] == 20
     flat.close(); empty.close(); tiny.close()
+
+
+def test_clustered_synthetic_fill_matches_restatement(rt):
+    ix = _native.Index(rt, 96, metric="L2")
+    ix.fill_synthetic_clustered(2000, seed=5, nclusters=37, spread=0.5, first_row=1000)
+    got = ix.get_rows(0, 2000)
+    want = orc.synth_clustered(2000, 96, seed=5, nclusters=37, spread=0.5, first_row=1000)
+    assert np.array_equal(bits(got), bits(want))
+    ix.close()
