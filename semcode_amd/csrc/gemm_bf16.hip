@@ -18,6 +18,8 @@
 //     4 consecutive output columns of one output row -> 8-byte bf16 stores, bias as one float4;
 //   * workgroup ids are remapped so that the tiles of one 128-row panel run on the same XCD (shared A
 //     panel stays in that XCD's L2).
+#include <cstdlib>
+
 #include "gemm_tile.h"
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
@@ -80,79 +82,103 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 }
 
 
-// ---- 256 x 256 x 64 tile variant (gemm_tile.h, second half); used when M % 256 == 0 and N % 256 == 0
-template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+// ---- 256 x 256 x 64 tile variant (gemm_tile.h, second half); used when M % 256 == 0 and N % 256 == 0.
+// PERSIST: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the (fire-and-forget) epilogue stores of
+// one tile drain while the LDS-DMA of the next tile is already in flight.  The K loop is register-tight (256
+// VGPRs), so everything the epilogue needs per lane is re-derived after the loop from an opaque copy of the lane id;
+// otherwise hipcc hoists that address arithmetic above the K loop and spills inside it.
+template <int EPI, int DBG>
+static __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, int vt, char* smem, int w, int lane) {
     const int wm = w >> 2, wn = w & 3;
-    const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const int m0 = mt * T_BM, n0 = nt * T_BN;
+    constexpr int STG_ROW = 64 * 4 + 16;  // bytes: 64 f32 + 16 B pad (conflict-free b128 writes)
+    {
+        const int tile = xcd_remap(vt, a.ntiles);
+        const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+        const int m0 = __builtin_amdgcn_readfirstlane(mt * T_BM), n0 = __builtin_amdgcn_readfirstlane(nt * T_BN);
 
-    f32x4 acc[4][8];  // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_tile256_mainloop<DBG & 3>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
-    if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
-        float sink = 0.f;
+        f32x4 acc[4][8];  // [ni][mi]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
-        if (sink == 12345.678f) a.C[0] = 1;
-        return;
-    }
-    // ---- epilogue through LDS: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row
-    // segments per store instruction); staging the wave's 128 x 64 f32 block in 4 passes of 32 rows lets it
-    // leave as whole 128-byte row segments, 16 B per lane.  The pipeline buffers are free here: after the
-    // main loop's last barrier no wave reads them again.  Staging is wave-private (LDS executes a wave's
-    // instructions in order), so no barrier is needed.
-    const int fr = lane & 15, fq = lane >> 4;
-    constexpr int STG_ROW = 64 * 4 + 16;  // bytes: 64 f32 + 16 B pad (conflict-free b128 writes)
-    char* stg = smem + w * (32 * STG_ROW);
-    f32x4 bias4[4];
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_tile256_mainloop<DBG & 3>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
+        if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
+            float sink = 0.f;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
-    const int prow = lane >> 3, c8 = (lane & 7) * 8;
-    const f32x4 bz = {0.f, 0.f, 0.f, 0.f};
-    (void)bz;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                f32x4 v = acc[ni][2 * p + h] + bias4[ni];
-                if (EPI == EPI_BIAS_GELU) {
-                    const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
-                    v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                }
-                *reinterpret_cast<f32x4*>(stg + (h * 16 + fr) * STG_ROW + (ni * 16 + 4 * fq) * 4) = v;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rl = j * 8 + prow;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4 + 16);
-            const size_t m = (size_t)(m0 + wm * 128 + p * 32 + rl);
-            const int n = n0 + wn * 64 + c8;
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (EPI == EPI_BIAS_RES) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.R + m * a.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += bf16_to_f32((bf16_t)rv[r]);
-            }
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
-            *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = o;
+                for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
+            if (sink == 12345.678f) a.C[0] = 1;
+            return;
         }
+        // ---- epilogue through LDS: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row
+        // segments per store instruction); staging the wave's 128 x 64 f32 block in 4 passes of 32 rows lets it
+        // leave as whole 128-byte row segments, 16 B per lane.  The pipeline buffers are free here: after the
+        // main loop's last barrier no wave reads them again.  Staging is wave-private (LDS executes a wave's
+        // instructions in order), so no barrier is needed inside the epilogue.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // opaque: nothing below can be computed before the K loop
+        __builtin_amdgcn_sched_barrier(0);
+        const int fr = ln & 15, fq = ln >> 4;
+        const int prow = ln >> 3, c8 = (ln & 7) * 8;
+        char* stg = smem + w * (32 * STG_ROW);
+        f32x4 bias4[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = acc[ni][2 * p + h] + bias4[ni];
+                    if (EPI == EPI_BIAS_GELU) {
+                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                    }
+                    *reinterpret_cast<f32x4*>(stg + (h * 16 + fr) * STG_ROW + (ni * 16 + 4 * fq) * 4) = v;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = j * 8 + prow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4 + 16);
+                const size_t m = (size_t)(m0 + wm * 128 + p * 32 + rl);
+                const int n = n0 + wn * 64 + c8;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (EPI == EPI_BIAS_RES) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.R + m * a.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bf16_to_f32((bf16_t)rv[r]);
+                }
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
+                *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gemm256_tile<EPI, DBG>(a, blockIdx.x, smem, w, lane);
+}
+
+// one workgroup per CU walking tiles blockIdx.x, + gridDim.x, ...
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_persistent_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+    for (int vt = blockIdx.x; vt < a.ntiles; vt += gridDim.x) {
+        if (vt != (int)blockIdx.x) __syncthreads();  // every wave is done reading its epilogue staging of the previous tile
+        gemm256_tile<EPI, 0>(a, vt, smem, w, lane);
     }
 }
 
@@ -160,7 +186,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
 bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && (M % G_BM) == 0 && (N % G_BN) == 0 && (K % G_BK) == 0; }
 
 static int g_gemm_dbg = 0;
-void sc_gemm_set_debug(int v) { g_gemm_dbg = v; }
+static bool g_gemm_persist = false, g_gemm_nopersist = false;
+void sc_gemm_set_debug(int v) { g_gemm_persist = (v == 8); g_gemm_nopersist = (v == 9); g_gemm_dbg = (v == 8 || v == 9) ? 0 : v; }
 static bool g_force_tile128 = false;
 void sc_gemm_force_tile128(bool on) { g_force_tile128 = on; }
 
@@ -195,6 +222,28 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
             else if (g_gemm_dbg == 2) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 2>), grid, block, lds256, s, a);
             else if (g_gemm_dbg == 4) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 4>), grid, block, lds256, s, a);
             else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 5>), grid, block, lds256, s, a);
+            return;
+        }
+        // The persistent walk (one workgroup per CU) is kept for experiments only (SC_GEMM_PERSIST=1): in the isolated
+        // microbench it wins 7-17 % on the GELU / residual epilogues (profiles/r1m_gemm_microbench.log), but inside the
+        // encoder pipeline, A/B on one device, it loses 6 % end to end (16.95k -> 15.97k chunks/s).
+        static const bool env_persist = getenv("SC_GEMM_PERSIST") != nullptr;
+        if (g_gemm_persist || env_persist) {
+            static int n_cus = 0;
+            static bool attrp = false;
+            if (!attrp) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                attrp = true;
+            }
+            dim3 pgrid((unsigned)(a.ntiles < n_cus ? a.ntiles : n_cus));
+            if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS_GELU>), pgrid, block, lds256, s, a);
+            else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS_RES>), pgrid, block, lds256, s, a);
+            else hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS>), pgrid, block, lds256, s, a);
             return;
         }
         if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_GELU>, grid, block, lds256, s, a);
