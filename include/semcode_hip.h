@@ -126,6 +126,20 @@ sc_status sc_encoder_embed_ids(sc_encoder* enc, const int32_t* ids, const int32_
 sc_status sc_encoder_embed_ids_dev(sc_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S,
                                    float* out_dev);
 
+/* ----------------------------------------------------------------- tokenizer ---- */
+typedef struct sc_tokenizer sc_tokenizer;
+/* Host-side WordPiece tokenizer (BERT scheme), the step the reference leaves to its provider's library (raw strings
+ * are handed over at indexer.py:150).  vocab_utf8 = contents of a vocab.txt (one token per line; needs [UNK] [CLS]
+ * [SEP]).  No GPU involved. */
+sc_status sc_tokenizer_create(const char* vocab_utf8, size_t nbytes, int32_t lowercase, sc_tokenizer** out);
+sc_status sc_tokenizer_destroy(sc_tokenizer* tok);
+sc_status sc_tokenizer_info(sc_tokenizer* tok, int32_t* vocab_size, int32_t* pad, int32_t* unk, int32_t* cls, int32_t* sep);
+/* texts i = bytes[offsets[i] .. offsets[i+1]) (UTF-8).  ids [n,S] ([CLS] pieces [SEP], truncated to min(max_tokens,S),
+ * padded with [PAD]), lens [n].  A text containing a non-ASCII byte is NOT tokenised: needs_fallback[i] = 1, lens[i] = 0
+ * (the Python tokenizer, which carries the Unicode rules, handles it).  threads <= 0: all hardware threads. */
+sc_status sc_tokenizer_encode(sc_tokenizer* tok, const char* bytes, const int64_t* offsets, int32_t n, int32_t max_tokens, int32_t S,
+                              int32_t* ids, int32_t* lens, uint8_t* needs_fallback, int32_t threads);
+
 /* Diagnostics: run ONE encoder kernel on host f32 data (rounded to bf16 on device, result widened
  * back to f32) so that the parity tests can check the GEMM and the attention kernel in isolation.
  * epi: 0 = bias, 1 = bias + erf-GELU, 2 = bias + residual R [M,N].  out [M,N] = A [M,K] * W [N,K]^T.

@@ -64,6 +64,10 @@ SIGNATURES = {
     "sc_encoder_info": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg)]),
     "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sc_tokenizer_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_tokenizer_info": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 5),
+    "sc_tokenizer_encode": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -341,6 +345,44 @@ class Encoder:
 
     def embed_ids_dev(self, ids_ptr: int, lens_ptr: int, B: int, S: int, out_ptr: int) -> None:
         _check(lib().sc_encoder_embed_ids_dev(self.handle, C.c_void_p(ids_ptr), C.c_void_p(lens_ptr), int(B), int(S), C.c_void_p(out_ptr)))
+
+
+class NativeTokenizer:
+    """C++ WordPiece (ASCII fast path, multi-threaded).  encode_batch returns which texts still need the Python tokenizer."""
+
+    def __init__(self, vocab_path, lowercase: bool = True):
+        data = Path(vocab_path).read_bytes()
+        self._h = C.c_void_p()
+        _check(lib().sc_tokenizer_create(data, len(data), 1 if lowercase else 0, C.byref(self._h)))
+        v = [C.c_int32() for _ in range(5)]
+        _check(lib().sc_tokenizer_info(self._h, *[C.byref(x) for x in v]))
+        self.vocab_size, self.pad_id, self.unk_id, self.cls_id, self.sep_id = (x.value for x in v)
+
+    def close(self) -> None:
+        if self._h:
+            lib().sc_tokenizer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+    def encode_batch(self, texts, max_tokens: int, S: int, threads: int = 0):
+        """-> (ids [n,S] int32, lens [n] int32, needs_fallback [n] bool)"""
+        raw = [t.encode("utf-8") for t in texts]
+        offsets = np.zeros(len(raw) + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in raw], out=offsets[1:])
+        blob = b"".join(raw)
+        n = len(raw)
+        ids = np.empty((n, S), dtype=np.int32)
+        lens = np.empty((n,), dtype=np.int32)
+        fb = np.empty((n,), dtype=np.uint8)
+        _check(lib().sc_tokenizer_encode(self._h, blob, offsets.ctypes.data_as(C.c_void_p), n, int(max_tokens), int(S),
+                                         ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), fb.ctypes.data_as(C.c_void_p), int(threads)))
+        return ids, lens, fb.astype(bool)
 
 
 def diag_gemm_bf16(rt: Runtime, A, W, bias, R=None, epi: int = 0) -> np.ndarray:

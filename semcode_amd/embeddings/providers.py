@@ -78,6 +78,7 @@ class MI355XEmbeddings:
         self._cfg = dict(_native.BERT_BASE)
         self._cfg.update(cfg or {})
         self.max_tokens = min(self.max_tokens, self._cfg["max_pos"])
+        self._fast_tokenizer: Any = None
         self._owns_runtime = runtime is None
         self._runtime = runtime or _native.Runtime(device=int(device if device is not None else getattr(settings, "mi355x_device", 0)))
         weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
@@ -92,6 +93,8 @@ class MI355XEmbeddings:
             self.tokenizer: Any = HashTokenizer(self._cfg["vocab"])
         else:
             self.tokenizer = WordPieceTokenizer(vocab)
+            if isinstance(vocab, (str, Path)):  # C++ fast path for ASCII texts; the Python tokenizer keeps the Unicode rules
+                self._fast_tokenizer = _native.NativeTokenizer(vocab)
         self.dimension = self._cfg["hidden"]
 
     # ---- LangChain Embeddings surface (lists of Python floats)
@@ -106,10 +109,26 @@ class MI355XEmbeddings:
         """texts -> [n, hidden] f32; tokenise on the host, forward on the device in batches."""
         out = np.empty((len(texts), self.dimension), dtype=np.float32)
         for start in range(0, len(texts), self.batch_size):
-            toks = [self.tokenizer.encode(t, self.max_tokens) for t in texts[start:start + self.batch_size]]
-            ids, lens = pack(toks, getattr(self.tokenizer, "pad_id", 0), self.max_tokens)
-            out[start:start + len(toks)] = self._encoder.embed_ids(ids, lens)
+            ids, lens = self.tokenize(texts[start:start + self.batch_size])
+            out[start:start + len(lens)] = self._encoder.embed_ids(ids, lens)
         return out
+
+    def tokenize(self, texts: Sequence[str]) -> "tuple[np.ndarray, np.ndarray]":
+        """texts -> (ids [n, S] int32 padded to the smallest sequence bucket that fits, lens [n])."""
+        if self._fast_tokenizer is None:
+            toks = [self.tokenizer.encode(t, self.max_tokens) for t in texts]
+            return pack(toks, getattr(self.tokenizer, "pad_id", 0), self.max_tokens)
+        from .tokenizer import bucket_for
+
+        smax = bucket_for(10 ** 9, self.max_tokens)
+        ids, lens, fallback = self._fast_tokenizer.encode_batch(texts, self.max_tokens, smax)
+        for i in np.nonzero(fallback)[0]:  # texts with non-ASCII characters
+            t = self.tokenizer.encode(texts[i], min(self.max_tokens, smax))
+            ids[i, : len(t)] = t
+            ids[i, len(t):] = self.tokenizer.pad_id
+            lens[i] = len(t)
+        S = bucket_for(int(lens.max()) if len(lens) else 1, self.max_tokens)
+        return np.ascontiguousarray(ids[:, :S]), lens
 
     def embed_ids_array(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512), lens [B] -> [B, hidden] f32."""

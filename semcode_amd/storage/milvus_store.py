@@ -18,8 +18,11 @@ this object.  Additions that do not break the reference surface: search_batch(),
 """
 from __future__ import annotations
 
+import json
 import logging
+import shutil
 import threading
+from pathlib import Path
 from typing import Any, Callable, Iterator, List, Optional, Sequence
 
 import numpy as np
@@ -120,6 +123,9 @@ class MilvusVectorStore:
             if self._collection is not None:
                 return
             self._collection = self._ensure_collection()
+            store_path = getattr(settings, "mi355x_store_path", None)
+            if store_path and (Path(store_path) / "manifest.json").exists() and not self._ids:
+                self.load(store_path)  # utility.has_collection(...) -> Collection(name).load() of the reference (milvus_store.py:51-54)
 
     def _ensure_collection(self) -> Any:
         if self._index_factory is not None:
@@ -256,6 +262,65 @@ class MilvusVectorStore:
                       "metadata": self._metadata[r]}
             hits.append(Hit(self._ids[r], d, fields, r))
         return hits
+
+    # ------------------------------------------------------------------ persistence (replaces Milvus' volume, docker-compose.yml:13-14)
+    def save(self, path: "str | Path") -> None:
+        """Write the collection to `path/` : manifest.json, vectors.f32 (row-major [rows, dim]), columns.jsonl
+        (id, repo, path, language, text, metadata per row).  Written to a temporary directory and renamed."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        path = Path(path)
+        tmp = path.with_name(path.name + ".tmp")
+        if tmp.exists():
+            shutil.rmtree(tmp)
+        tmp.mkdir(parents=True)
+        with self._lock:
+            n = len(self._ids)
+            with open(tmp / "vectors.f32", "wb") as f:
+                for start in range(0, n, 65536):
+                    m = min(65536, n - start)
+                    np.ascontiguousarray(self._collection.get_rows(start, m), dtype="<f4").tofile(f)
+            with open(tmp / "columns.jsonl", "w", encoding="utf-8") as f:
+                for r in range(n):
+                    f.write(json.dumps({"id": self._ids[r], "repo": self._repos[r], "path": self._paths[r], "language": self._languages[r],
+                                        "text": self._texts[r], "metadata": self._metadata[r]}, ensure_ascii=False) + "\n")
+            manifest = {"format": "semcode_amd.collection.v1", "collection_name": self.collection_name, "dim": self.dim, "rows": n,
+                        "metric": self.metric, "index_type": self.index_type, "nlist": self.nlist, "nprobe": self.nprobe}
+            (tmp / "manifest.json").write_text(json.dumps(manifest, indent=1))
+        if path.exists():
+            shutil.rmtree(path)
+        tmp.rename(path)
+
+    def load(self, path: "str | Path") -> None:
+        """Replace the collection's content with a directory written by save() (connect() first)."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        path = Path(path)
+        manifest = json.loads((path / "manifest.json").read_text())
+        if manifest.get("format") != "semcode_amd.collection.v1":
+            raise ValueError(f"{path}: unknown collection format {manifest.get('format')!r}")
+        if manifest["dim"] != self.dim:
+            raise ValueError(f"{path}: stored dim {manifest['dim']} != collection dim {self.dim}")
+        with self._lock:
+            if len(self._ids):
+                raise RuntimeError("load() needs an empty collection")
+            n = manifest["rows"]
+            vec = np.memmap(path / "vectors.f32", dtype="<f4", mode="r", shape=(n, self.dim)) if n else np.zeros((0, self.dim), np.float32)
+            for start in range(0, n, 65536):
+                self._collection.add(np.asarray(vec[start:start + 65536], dtype=np.float32))
+            with open(path / "columns.jsonl", encoding="utf-8") as f:
+                for line in f:
+                    c = json.loads(line)
+                    self._row_of[c["id"]] = len(self._ids)
+                    self._ids.append(c["id"])
+                    self._repos.append(c["repo"])
+                    self._paths.append(c["path"])
+                    self._languages.append(c["language"])
+                    self._texts.append(c["text"])
+                    self._metadata.append(c["metadata"])
+            if len(self._ids) != n:
+                raise ValueError(f"{path}: columns.jsonl holds {len(self._ids)} rows, manifest says {n}")
+            self._needs_train = True
 
     def __iter__(self) -> Iterator:  # pragma: no cover - convenience
         return iter(self._ids)

@@ -34,6 +34,9 @@ class FakeIndex:
         self.calls.append(("overwrite", [int(r) for r in rows]))
         self.X[np.asarray(rows)] = v
 
+    def get_rows(self, first, n):
+        return self.X[first:first + n].copy()
+
     def search(self, q, k=10, nprobe=16):
         s = q @ self.X.T
         order = np.argsort(-s, axis=1, kind="stable")[:, :k]
@@ -169,3 +172,26 @@ def test_build_payloads_progress_and_mapping():
     emb, seen = DummyEmbedding(), []
     assert build_payloads("demo", root, [], emb, progress=lambda a, b: seen.append((a, b))) == []
     assert seen == [(0, 0)] and emb.batches == []
+
+
+def test_save_and_load_round_trip(tmp_path):
+    s = make_store()
+    s.connect()
+    s.upsert_embeddings([payload(i, np.eye(4)[i % 4] * (i + 1)) for i in range(10)])
+    s.upsert_embeddings([payload(3, [9, 9, 9, 9])])  # an overwritten row must persist as overwritten
+    s.save(tmp_path / "col")
+    assert sorted(p.name for p in (tmp_path / "col").iterdir()) == ["columns.jsonl", "manifest.json", "vectors.f32"]
+    t = make_store()
+    t.connect()
+    t.load(tmp_path / "col")
+    assert len(t) == 10 and np.array_equal(t._collection.X, s._collection.X)
+    a, b = next(iter(s.search([1, 1, 1, 1], top_k=4))), next(iter(t.search([1, 1, 1, 1], top_k=4)))
+    assert [h.id for h in a] == [h.id for h in b] and a[0].id == "id3"
+    assert b[0].entity.get("metadata")["language"] == "python"
+    # re-ingest after load is still idempotent by primary key
+    t.upsert_embeddings([payload(3, [1, 0, 0, 0])])
+    assert len(t) == 10
+    wrong = MilvusVectorStore(dim=5, index_factory=lambda **kw: FakeIndex(kw["dim"]))
+    wrong.connect()
+    with pytest.raises(ValueError):
+        wrong.load(tmp_path / "col")

@@ -76,3 +76,39 @@ def test_embed_store_search_round_trip(rt):
     assert r[:, 0].tolist() == list(range(40))
     cos.close()
     emb.close()
+
+
+def test_store_save_load_round_trip_on_device(rt, tmp_path):
+    rng = np.random.default_rng(0)
+    vecs = rng.standard_normal((300, 128)).astype(np.float32)
+    payloads = [EmbeddingPayload(id=f"k{i}", text=f"t{i}", vector=vecs[i].tolist(),
+                                 metadata={"repo": "r", "path": f"p{i}", "language": "cpp", "start_line": i, "end_line": i + 1, "symbol": None})
+                for i in range(300)]
+    a = MilvusVectorStore(dim=128, metric="L2", index_type="FLAT", runtime=rt)
+    a.connect()
+    a.upsert_embeddings(payloads)
+    a.save(tmp_path / "semcode_chunks")
+    b = MilvusVectorStore(dim=128, metric="L2", index_type="FLAT", runtime=rt)
+    b.connect()
+    b.load(tmp_path / "semcode_chunks")
+    q = vecs[:7] + 0.01
+    da, ra = a.search_batch(q, top_k=5)
+    db, rb = b.search_batch(q, top_k=5)
+    assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    assert next(iter(b.search(vecs[42].tolist(), top_k=1)))[0].id == "k42"
+    a.close(); b.close()
+
+
+def test_provider_with_vocab_uses_native_tokenizer(rt, tmp_path):
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "def", "return", "x", "y", "f", "(", ")", ":", "+", "1", "##1", "caf", "##e"]
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(words) + "\n", encoding="utf-8")
+    emb = MI355XEmbeddings(cfg=dict(SMALL, vocab=len(words)), vocab=vocab, runtime=rt, synth_seed=1)
+    assert emb._fast_tokenizer is not None
+    texts = ["def f(x): return x + 1", "def f(y): return y + 11", "café x"]  # the third goes through the Python fallback
+    ids, lens = emb.tokenize(texts)
+    py = [emb.tokenizer.encode(t, emb.max_tokens) for t in texts]
+    assert [ids[i, : lens[i]].tolist() for i in range(3)] == py and ids.shape[1] == 32
+    v = emb.embed_documents_array(texts)
+    assert v.shape == (3, 128) and np.isfinite(v).all() and not np.allclose(v[0], v[1])
+    emb.close()

@@ -74,3 +74,30 @@ def test_factory_dispatch_and_error_types(monkeypatch):
 
         with pytest.raises(_native.ScError):
             EmbeddingProviderFactory.create(provider="mi355x")
+
+
+def test_native_tokenizer_matches_python_and_flags_non_ascii(vocab_file):
+    import time
+
+    from semcode_amd import _native
+
+    nat = _native.NativeTokenizer(vocab_file)
+    py = WordPieceTokenizer(vocab_file)
+    assert (nat.vocab_size, nat.pad_id, nat.unk_id, nat.cls_id, nat.sep_id) == (py.vocab_size, py.pad_id, py.unk_id, py.cls_id, py.sep_id)
+    ascii_texts = [t for t in TEXTS if t.isascii()] + ["a\x00b\x01c\x7f d", "\t\n  ", "x=y+1;print(x)  #done", " ".join(["hello world"] * 300)]
+    for max_tokens, S in ((64, 64), (32, 64), (512, 512)):
+        ids, lens, fb = nat.encode_batch(ascii_texts, max_tokens, S, threads=3)
+        assert not fb.any()
+        for i, t in enumerate(ascii_texts):
+            want = py.encode(t, min(max_tokens, S))
+            assert ids[i, : lens[i]].tolist() == want, (t[:40], max_tokens)
+            assert (ids[i, lens[i]:] == nat.pad_id).all()
+    mixed = ["plain ascii", "café", "中文", "naive"]
+    ids, lens, fb = nat.encode_batch(mixed, 64, 64)
+    assert fb.tolist() == [False, True, True, False] and lens[1] == 0
+    # throughput sanity: the C++ path is much faster than the per-character Python path
+    big = ["def f%d(x):\\n    return x + %d  # helper number %d\\n" % (i, i, i) * 20 for i in range(400)]
+    t0 = time.perf_counter(); nat.encode_batch(big, 256, 256); t_nat = time.perf_counter() - t0
+    t0 = time.perf_counter(); [py.encode(t, 256) for t in big[:40]]; t_py = (time.perf_counter() - t0) * 10
+    assert t_nat < t_py / 5, (t_nat, t_py)
+    nat.close()
