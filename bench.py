@@ -85,7 +85,7 @@ def timed(ctx, fn, nsteps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if ctx.world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -188,10 +188,19 @@ def bench_scan(ctx, args) -> dict:
     def step(nq=Q):
         ix.search_dev(q.data_ptr(), nq, k, out_d.data_ptr(), out_r.data_ptr())
         if world > 1:  # the one exchange step of the path: per-shard [Q,k] -> every rank, then host merge
-            ctx.dist.all_gather_into_tensor(all_d, out_d)
-            ctx.dist.all_gather_into_tensor(all_r, out_r)
+            if ctx.backend == "nccl":
+                ctx.dist.all_gather_into_tensor(all_d, out_d)
+                ctx.dist.all_gather_into_tensor(all_r, out_r)
+                gd, gr = all_d, all_r
+            else:  # rehearsal backend: gather on the host
+                hd, hr = out_d.cpu(), out_r.cpu()
+                ld, lr = [torch.empty_like(hd) for _ in range(world)], [torch.empty_like(hr) for _ in range(world)]
+                ctx.dist.all_gather(ld, hd)
+                ctx.dist.all_gather(lr, hr)
+                gd, gr = torch.stack(ld), torch.stack(lr)
             if rank == 0:
-                _native.topk_merge_host(args.metric_type, all_d.cpu().numpy(), all_r.cpu().numpy())
+                return _native.topk_merge_host(args.metric_type, gd.cpu().numpy(), gr.cpu().numpy())
+        return None
 
     for _ in range(args.warmup):
         step()
@@ -299,13 +308,20 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if ctx.world == 1 and args.gpus > 1:
         raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
+    # one process per GPU; SEMCODE_BENCH_BACKEND=gloo lets several ranks share one device (rehearsal on a 1-GPU box)
+    backend = os.environ.get("SEMCODE_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     ctx.dev = torch.device("cuda", local)
     ctx.dist = None
+    ctx.backend = backend
     if ctx.world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=ctx.dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=ctx.dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
         ctx.dist = dist
     stream = torch.cuda.Stream(device=ctx.dev)
     ctx.rt = _native.Runtime(device=local, stream=stream.cuda_stream)

@@ -33,6 +33,7 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldr, ldc;
     int tiles_n;       // N / 128
     int ntiles;        // (M/128) * tiles_n
+    int order;         // 256-tile kernels: tile walk (see gemm256_tile)
 };
 
 template <int EPI>
@@ -92,8 +93,17 @@ static __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, int vt, c
     const int wm = w >> 2, wn = w & 3;
     constexpr int STG_ROW = 64 * 4 + 16;  // bytes: 64 f32 + 16 B pad (conflict-free b128 writes)
     {
-        const int tile = xcd_remap(vt, a.ntiles);
-        const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+        // tile order: bit 0 of a.order = skip the XCD remap; a.order >> 1 = G: walk column-major inside groups of G row panels
+        const int tile = (a.order & 1) ? vt : xcd_remap(vt, a.ntiles);
+        int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+        const int G = a.order >> 1;
+        if (G > 1) {
+            const int tiles_m = a.ntiles / a.tiles_n;
+            const int gsz = G * a.tiles_n, g = tile / gsz, r = tile - g * gsz;
+            const int rows_here = (g * G + G <= tiles_m) ? G : tiles_m - g * G;  // last group may be short
+            mt = g * G + r % rows_here;
+            nt = r / rows_here;
+        }
         const int m0 = __builtin_amdgcn_readfirstlane(mt * T_BM), n0 = __builtin_amdgcn_readfirstlane(nt * T_BN);
 
         f32x4 acc[4][8];  // [ni][mi]
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(512) void gemm256_persistent_kernel(GemmArgs a) {
 // M, N multiples of 128; K multiple of 64; all leading dimensions multiples of 8 elements.
 bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && (M % G_BM) == 0 && (N % G_BN) == 0 && (K % G_BK) == 0; }
 
+static int g_gemm_order = 16;  // XCD remap + column-major walk inside groups of 8 row panels (profiles/r1n_gemm_tile_order.log)
+void sc_gemm_set_order(int v) { g_gemm_order = v; }
 static int g_gemm_dbg = 0;
 static bool g_gemm_persist = false, g_gemm_nopersist = false;
 void sc_gemm_set_debug(int v) { g_gemm_persist = (v == 8); g_gemm_nopersist = (v == 9); g_gemm_dbg = (v == 8 || v == 9) ? 0 : v; }
@@ -196,6 +208,8 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     GemmArgs a;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
+    static const char* env_order = getenv("SC_GEMM_ORDER");  // A/B experiments
+    a.order = env_order ? atoi(env_order) : g_gemm_order;
     static bool attr_done = false;
     if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
         a.tiles_n = N / T_BN;
@@ -216,11 +230,13 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+
                 attrd = true;
             }
             if (g_gemm_dbg == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 1>), grid, block, lds256, s, a);
             else if (g_gemm_dbg == 2) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 2>), grid, block, lds256, s, a);
             else if (g_gemm_dbg == 4) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 4>), grid, block, lds256, s, a);
+
             else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 5>), grid, block, lds256, s, a);
             return;
         }

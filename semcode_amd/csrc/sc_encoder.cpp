@@ -30,6 +30,7 @@ void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, f
 void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s);
 
 void sc_gemm_set_debug(int v);
+void sc_gemm_set_order(int v);
 void sc_gemm_force_tile128(bool on);
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
@@ -398,7 +399,8 @@ extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, 
     SC_HIP(hipMemsetAsync(db.p, 0, (size_t)N * 4, s));
     SC_HIP(hipMemsetAsync(dr.p, 0, (size_t)nc * 2, s));
     sc_gemm_force_tile128(variant == 128);
-    sc_gemm_set_debug(variant == 128 ? 0 : variant);
+    sc_gemm_set_debug((variant == 128 || variant >= 1000) ? 0 : variant);
+    sc_gemm_set_order(variant >= 1000 ? variant - 1000 : 16);  // variants 1000+o: tile order o with the real epilogue
     hipEvent_t e0, e1;
     SC_HIP(hipEventCreate(&e0));
     SC_HIP(hipEventCreate(&e1));
@@ -409,6 +411,7 @@ extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, 
     hipError_t he = hipStreamSynchronize(s);
     sc_gemm_force_tile128(false);
     sc_gemm_set_debug(0);
+    sc_gemm_set_order(16);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0);

@@ -183,7 +183,14 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    const int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;
+    int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;
+    {   // column-major walk inside groups of 8 row panels (same order as the encoder GEMMs; -12 % there)
+        const int G = 8, rtiles = a.ntiles / a.qtiles;
+        const int gsz = G * a.qtiles, g = tile / gsz, r = tile - g * gsz;
+        const int rows_here = (g * G + G <= rtiles) ? G : rtiles - g * G;
+        rt = g * G + r % rows_here;
+        qt = r / rows_here;
+    }
     const int64_t m0 = a.row0 + (int64_t)rt * T_BM;
     const int n0 = qt * T_BN;
     float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
