@@ -19,7 +19,7 @@
 //     fmaf chain per (row, query) in the canonical k order of oracle/sc_oracle.c sc_oracle_dot;
 //   * per tile each lane holds 4 scores of one query: threshold filter against the wave's running
 //     k-th best key, rare LDS append, rank-sort compaction when a candidate buffer fills;
-//   * each wave writes its sorted k best keys per query; topk_merge.hip reduces the lists.
+//   * at the end the workgroup merges its 4 waves' lists; topk_merge.hip reduces the per-workgroup lists.
 #include "sc_common.h"
 
 #define SCAN_WAVES 4
@@ -263,15 +263,32 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         }
     }
 
-    // ---- flush: sorted k best per query slot -> partial[grp][wg*4 + w][slot][k]
-    uint64_t* out = a.partial + (((size_t)grp * gridDim.x + blockIdx.x) * SCAN_WAVES + w) * (size_t)a.qt * a.k;
+    // ---- flush: every wave sorts its slots; the workgroup then merges its 4 lists per slot (rank among the union,
+    // keys are unique) and writes ONE sorted list: partial[grp][wg][slot][k]
+    for (int c = 0; c < nq; ++c) wave_compact(cand_w + c * a.cap, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+    __syncthreads();
+    uint64_t* out = a.partial + ((size_t)grp * gridDim.x + blockIdx.x) * (size_t)a.qt * a.k;
+    lds_u64p cand_all = (lds_u64p)(smem + L.cand);
+    lds_u32p cnt_all = (lds_u32p)(smem + L.cnt);
     for (int c = 0; c < a.qt; ++c) {
-        int m = 0;
-        if (c < nq) {
-            wave_compact(cand_w + c * a.cap, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
-            m = (int)cnt_w[c];
+        int m[SCAN_WAVES], total = 0;
+#pragma unroll
+        for (int v = 0; v < SCAN_WAVES; ++v) {
+            m[v] = c < nq ? (int)cnt_all[v * 16 + c] : 0;
+            total += m[v];
         }
-        for (int e = lane; e < a.k; e += 64) out[(size_t)c * a.k + e] = e < m ? cand_w[c * a.cap + e] : SC_KEY_MAX;
+        for (int e = tid; e < total; e += 256) {
+            int v = 0, idx = e;
+            while (idx >= m[v]) { idx -= m[v]; ++v; }
+            const uint64_t key = cand_all[(v * a.qt + c) * a.cap + idx];
+            int rank = 0;
+#pragma unroll
+            for (int u = 0; u < SCAN_WAVES; ++u)
+                for (int j = 0; j < m[u]; ++j) rank += (cand_all[(u * a.qt + c) * a.cap + j] < key) ? 1 : 0;
+            if (rank < a.k) out[(size_t)c * a.k + rank] = key;
+        }
+        const int have = total < a.k ? total : a.k;
+        for (int e = have + tid; e < a.k; e += 256) out[(size_t)c * a.k + e] = SC_KEY_MAX;
     }
 }
 
@@ -287,7 +304,7 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
     p->groups = (Q + qt - 1) / qt;
     p->nwg = cus > 0 ? cus : 256;
     p->cap = cap;
-    p->lists = p->nwg * SCAN_WAVES;
+    p->lists = p->nwg;  // one merged list per workgroup
     p->lds = scan_lds_layout(ld, qt, cap, nprobe).total;
     p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t);
     return true;

@@ -96,9 +96,77 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(int metric, c
     }
 }
 
+// Tree merge in LDS: all `lists` sorted k-lists of one query are loaded once, then halved log2(lists) times; in each
+// round a thread merges two sorted lists with two pointers (k steps).  Used whenever 2 * lists * k keys fit in LDS.
+__global__ __launch_bounds__(MERGE_THREADS) void topk_tree_merge_kernel(int metric, const uint64_t* __restrict__ partial, int lists, int qt, int Q,
+                                                                         int k, int64_t row_base, float* __restrict__ out_dist,
+                                                                         int64_t* __restrict__ out_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t tm_lds[];  // [2][lists * k]
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int grp = q / qt, slot = q - grp * qt;
+    const uint64_t* base = partial + ((size_t)grp * lists * qt + slot) * (size_t)k;
+    const size_t lstride = (size_t)qt * k;
+    uint64_t* buf0 = tm_lds;
+    uint64_t* buf1 = tm_lds + (size_t)lists * k;
+    for (int i = tid; i < lists * k; i += MERGE_THREADS) {
+        const int l = i / k, j = i - l * k;
+        buf0[i] = base[(size_t)l * lstride + j];
+    }
+    __syncthreads();
+    int n = lists;
+    uint64_t* src = buf0;
+    uint64_t* dst = buf1;
+    while (n > 1) {
+        const int pairs = (n + 1) >> 1;
+        for (int t = tid; t < pairs; t += MERGE_THREADS) {
+            const uint64_t* A = src + (size_t)(2 * t) * k;
+            uint64_t* O = dst + (size_t)t * k;
+            if (2 * t + 1 >= n) {
+                for (int j = 0; j < k; ++j) O[j] = A[j];
+            } else {
+                const uint64_t* B = A + k;
+                int ia = 0, ib = 0;
+                for (int j = 0; j < k; ++j) {  // both lists hold k entries (SC_KEY_MAX padded), so neither index runs past k before j does
+                    const uint64_t x = A[ia], y = B[ib];
+                    const bool ta = x <= y;
+                    O[j] = ta ? x : y;
+                    ia += ta ? 1 : 0;
+                    ib += ta ? 0 : 1;
+                }
+            }
+        }
+        __syncthreads();
+        uint64_t* tmp = src; src = dst; dst = tmp;
+        n = pairs;
+    }
+    for (int j = tid; j < k; j += MERGE_THREADS) {
+        const size_t o = (size_t)q * k + j;
+        const uint64_t key = lists > 0 ? src[j] : SC_KEY_MAX;
+        if (key != SC_KEY_MAX) {
+            out_dist[o] = sc_key_score(metric, key);
+            out_rows[o] = row_base + (int64_t)(uint32_t)key;
+        } else {
+            out_dist[o] = (metric == SC_METRIC_L2) ? __builtin_inff() : -__builtin_inff();
+            out_rows[o] = -1;
+        }
+    }
+}
+
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k, int64_t row_base,
                           float* out_dist, int64_t* out_rows, hipStream_t s) {
     (void)groups;
+    const size_t tree_lds = (size_t)2 * lists * k * sizeof(uint64_t);
+    if (lists > 0 && tree_lds <= 128 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(topk_tree_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), tree_lds, s, metric, partial, lists, qt, Q, k, row_base,
+                           out_dist, out_rows);
+        return;
+    }
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), 0, s, metric, partial, lists, qt, Q, k, row_base,
                        out_dist, out_rows);
 }
