@@ -139,127 +139,153 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // qkv: [tokens, 3H] bf16 rows = [Q | K | V], head h at columns h*64 of each third.  ctx: [tokens, H].
 // KT = S / 32 key tiles.  LDS: K image [S][64] with chunk ^= (row>>1)&7, V image [S][64] with
 // chunk ^= ((row>>1)&1)<<2 (conflict-free for ds_read_b128 rows / ds_read_b64_tr_b16 blocks).
-// One 32-row query block of one wave.  FULL = every key of the padded sequence is real (len == S): no
-// per-tile guards or masks, so hipcc can interleave the MFMAs of different key tiles with the softmax VALU.
+// One 32-row query block of one wave, keys processed in groups of 4 tiles (128 keys) with an online softmax, so
+// that only 64 score registers are live (S = 256 runs 2 workgroups per CU, S = 512 no longer spills).
+// FULL = every key of the padded sequence is real (len == S): no per-tile guards or masks.
 template <int KT, bool FULL>
-static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* invl_w, char* ostg,
+static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, char* ostg,
                                                         bf16_t* obase, int H, int len, int nkt, int lane) {
+    constexpr int GK = KT < 4 ? KT : 4;   // key tiles per group
+    constexpr int NG = (KT + GK - 1) / GK;
     const int l31 = lane & 31, hh = lane >> 5;
     const float sl2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
     const int tail = len & 31;                           // != 0: the last real key tile is partially masked
-    // S^T tiles: st[t][r] = score(key = 32 t + (r&3) + 8 (r>>2) + 4 hh, query = l31)
-    f32x16 st[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (FULL || t < nkt) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int krow = 32 * t + l31;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int c = 2 * ks + hh;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
-            }
-            st[t] = acc;
-        }
-    }
-    // masked softmax over keys (registers + the other half-wave); only the last real tile needs the mask
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (FULL || t < nkt) {
-            if (!FULL && t == nkt - 1 && tail) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh < len) mx = fmaxf(mx, st[t][r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-            }
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mb = mx * sl2;
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (FULL || t < nkt) {
-            const bool masked = !FULL && (t == nkt - 1) && tail;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], sl2, -mb));
-                if (masked && !(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh < len)) p = 0.f;
-                st[t][r] = p;
-                sum += p;
-            }
-        }
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    invl_w[l31] = 1.0f / sum;
-
-    // O = P V: A operand = P straight from the score registers (k order of step s:
-    // key = 32 t + 16 s + 8 (j>>2) + 4 hh + (j&3)), B operand = V by transposed LDS reads
+    float m_run = -3.0e38f, l_run = 0.f;
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (FULL || t < nkt) {
+    for (int g = 0; g < NG; ++g) {
+        if (!FULL && g * GK >= nkt) continue;  // wave-uniform: nothing real in this group
+        // S^T tiles of the group: st[i][r] = score(key = 32 t + (r&3) + 8 (r>>2) + 4 hh, query = l31), t = g*GK + i
+        f32x16 st[GK];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 pp;
+        for (int i = 0; i < GK; ++i) {
+            const int t = g * GK + i;
+            if (FULL || t < nkt) {
+                f32x16 acc;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pp[j] = pack_bf16x2(st[t][8 * s + 2 * j], st[t][8 * s + 2 * j + 1]);
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pp);
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const int krow = 32 * t + l31;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    bf16x8 vf;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = 2 * ks + hh;
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+                }
+                st[i] = acc;
+            }
+        }
+        float mx = m_run;
 #pragma unroll
-                    for (int piece = 0; piece < 2; ++piece) {
-                        const int row = 32 * t + 16 * s + 8 * piece + 4 * hh + ((lane & 15) >> 2);
-                        const int d0 = 32 * dt + 16 * ((lane >> 4) & 1);
-                        const int chunk = (d0 >> 3) + ((lane & 3) >> 1);
-                        const int sw = chunk ^ (((row >> 1) & 1) << 2);
-                        typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
-                        const s16x4 got = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(Vl + row * 128 + sw * 16 + 8 * (lane & 1)));
-                        vf[4 * piece + 0] = got[0];
-                        vf[4 * piece + 1] = got[1];
-                        vf[4 * piece + 2] = got[2];
-                        vf[4 * piece + 3] = got[3];
+        for (int i = 0; i < GK; ++i) {
+            const int t = g * GK + i;
+            if (FULL || t < nkt) {
+                if (!FULL && t == nkt - 1 && tail) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh < len) mx = fmaxf(mx, st[i][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[i][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = mx * sl2;
+        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sl2, -mb));  // first group: exp2(-huge) = 0, and O, l are 0 anyway
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < GK; ++i) {
+            const int t = g * GK + i;
+            if (FULL || t < nkt) {
+                const bool masked = !FULL && (t == nkt - 1) && tail;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[i][r], sl2, -mb));
+                    if (masked && !(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh < len)) p = 0.f;
+                    st[i][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = fmaf(l_run, alpha, sum);
+        m_run = mx;
+        if (g > 0) {  // rescale O: its rows are queries (r&3) + 8 (r>>2) + 4 hh, alpha lives on lane q -> exchange through LDS
+            xch[l31] = alpha;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 al = *reinterpret_cast<const f32x4*>(xch + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { o0[4 * g4 + c] *= al[c]; o1[4 * g4 + c] *= al[c]; }
+            }
+        }
+        // O += P V: A operand = P straight from the score registers (k order of step s:
+        // key = 32 t + 16 s + 8 (j>>2) + 4 hh + (j&3)), B operand = V by transposed LDS reads
+#pragma unroll
+        for (int i = 0; i < GK; ++i) {
+            const int t = g * GK + i;
+            if (FULL || t < nkt) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 pp;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[j] = pack_bf16x2(st[i][8 * s + 2 * j], st[i][8 * s + 2 * j + 1]);
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pp);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        bf16x8 vf;
+#pragma unroll
+                        for (int piece = 0; piece < 2; ++piece) {
+                            const int row = 32 * t + 16 * s + 8 * piece + 4 * hh + ((lane & 15) >> 2);
+                            const int d0 = 32 * dt + 16 * ((lane >> 4) & 1);
+                            const int chunk = (d0 >> 3) + ((lane & 3) >> 1);
+                            const int sw = chunk ^ (((row >> 1) & 1) << 2);
+                            typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
+                            const s16x4 got = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(Vl + row * 128 + sw * 16 + 8 * (lane & 1)));
+                            vf[4 * piece + 0] = got[0];
+                            vf[4 * piece + 1] = got[1];
+                            vf[4 * piece + 2] = got[2];
+                            vf[4 * piece + 3] = got[3];
+                        }
+                        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o0, 0, 0, 0);
+                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o1, 0, 0, 0);
                     }
-                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o0, 0, 0, 0);
-                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o1, 0, 0, 0);
                 }
             }
         }
     }
-    // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS
-    // (wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
+    // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS 16 query
+    // rows at a time (wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
+    xch[l31] = 1.0f / l_run;
     bf16_t* og = reinterpret_cast<bf16_t*>(ostg);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 il = *reinterpret_cast<const f32x4*>(invl_w + 8 * g + 4 * hh);
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int q = 8 * g + 4 * hh + c;
-            og[q * 64 + l31] = (bf16_t)(pack_bf16x2(o0[4 * g + c] * il[c], 0.f) & 0xFFFFu);
-            og[q * 64 + 32 + l31] = (bf16_t)(pack_bf16x2(o1[4 * g + c] * il[c], 0.f) & 0xFFFFu);
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g4 = 2 * half + gg;
+            const f32x4 il = *reinterpret_cast<const f32x4*>(xch + 8 * g4 + 4 * hh);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ql = 8 * gg + 4 * hh + c;  // row inside this half
+                og[ql * 64 + l31] = (bf16_t)(pack_bf16x2(o0[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
+                og[ql * 64 + 32 + l31] = (bf16_t)(pack_bf16x2(o1[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = 8 * j + (lane >> 3), c = lane & 7;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ostg + q * 128 + c * 16);
-        *reinterpret_cast<bf16x8*>(obase + (size_t)q * H + c * 8) = v;
+        for (int j = 0; j < 2; ++j) {
+            const int ql = 8 * j + (lane >> 3), c = lane & 7;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(ostg + ql * 128 + c * 16);
+            *reinterpret_cast<bf16x8*>(obase + (size_t)(16 * half + ql) * H + c * 8) = v;
+        }
     }
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
-                                                         bf16_t* __restrict__ ctx) {
+__global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
+                                                            bf16_t* __restrict__ ctx) {
     constexpr int S = KT * 32;
     constexpr int NQB = (KT + 3) / 4;  // query blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,8 +293,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     char* Vl = smem + S * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* invl_w = reinterpret_cast<float*>(smem + 2 * S * 128) + w * 32;  // [4 waves][32]
-    char* ostg = smem + 2 * S * 128 + 512 + w * 4096;                       // per-wave [32 q][64 d] bf16 output staging
+    float* xch = reinterpret_cast<float*>(smem + 2 * S * 128) + w * 32;  // [4 waves][32] alpha / 1/l exchange
+    char* ostg = smem + 2 * S * 128 + 512 + w * 2048;                    // per-wave [16 q][64 d] bf16 output staging
     const int head = blockIdx.x, b = blockIdx.y;
     const int ld = 3 * H;
     const bf16_t* base = qkv + (size_t)b * S * ld + head * 64;
@@ -278,8 +304,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int nkt = (len + 31) >> 5;  // key tiles holding at least one real key; later tiles are skipped entirely
 
     // ---- stage K then V rows [0, 32 nkt) of this (chunk, head): pieces of 8 rows x 128 B = 1 KiB
-    int nk_pieces = 0;
-    for (int piece = w; piece < nkt * 4; piece += 4, ++nk_pieces) {
+    for (int piece = w; piece < nkt * 4; piece += 4) {
         const int p = piece * 64 + lane;
         const int r = p >> 3, ck = (p & 7) ^ ((r >> 1) & 7);
         __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + H + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
@@ -310,8 +335,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         const int qb = w + 4 * i;
         if (qb < KT) {
             bf16_t* obase = ctx + (size_t)(b * S + qb * 32) * H + head * 64;
-            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true>(qf[i], Kl, Vl, invl_w, ostg, obase, H, len, nkt, lane);
-            else attention_qblock<KT, false>(qf[i], Kl, Vl, invl_w, ostg, obase, H, len, nkt, lane);
+            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane);
+            else attention_qblock<KT, false>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane);
         }
     }
 }
@@ -376,7 +401,7 @@ void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, cons
 }
 template <int KT>
 static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, void* ctx, hipStream_t s) {
-    const size_t lds = (size_t)KT * 32 * 256 + 512 + 4 * 4096;
+    const size_t lds = (size_t)KT * 32 * 256 + 512 + 4 * 2048;
     static bool done = false;
     if (!done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
