@@ -104,12 +104,17 @@ typedef struct sc_encoder_cfg {
     float ln_eps;
     int32_t normalize;    /* 1 = L2-normalise the pooled vector                               */
     uint64_t synth_seed;  /* used only when no weight blob is given (benchmarks)              */
+    int32_t pos_type;     /* 0 = learned absolute position table (BERT); 1 = ALiBi: no table, scores get
+                             -slope_h * |i - j| (jina-embeddings-v2 family named in the reference README) */
+    int32_t ffn_type;     /* 0 = Linear-GELU-Linear (BERT); 1 = GEGLU: W1 is [2*ffn, H] (gate rows first, then up
+                             rows), hidden = gelu(gate) * up, b1 is [2*ffn] (zeros for bias-free models)      */
 } sc_encoder_cfg;
 
 /* Size in bytes of the f32 weight blob sc_encoder_create expects for cfg.  Blob order (all f32,
  * torch.nn.Linear layout [out, in]): word_emb [vocab,H], pos_emb [max_pos,H], type_emb [type_vocab,H],
  * emb_ln_gamma [H], emb_ln_beta [H], then per layer: Wq [H,H], bq, Wk, bk, Wv, bv, Wo [H,H], bo,
- * ln1_gamma, ln1_beta, W1 [ffn,H], b1 [ffn], W2 [H,ffn], b2 [H], ln2_gamma, ln2_beta. */
+ * ln1_gamma, ln1_beta, W1 [ffn,H], b1 [ffn], W2 [H,ffn], b2 [H], ln2_gamma, ln2_beta.
+ * pos_type 1 drops pos_emb from the blob; ffn_type 1 makes W1 [2*ffn,H] and b1 [2*ffn]. */
 sc_status sc_encoder_blob_bytes(const sc_encoder_cfg* cfg, int64_t* out);
 /* Replaces EmbeddingProviderFactory.create() loading a model (providers.py:69-100): uploads the
  * weights (converted to bf16 on device).  weights_blob == NULL: synthetic weights 0.02*N(0,1) from

@@ -36,7 +36,7 @@ class _Cfg(C.Structure):
 class EncoderCfg(C.Structure):
     _fields_ = [("vocab", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32),
                 ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("ln_eps", C.c_float), ("normalize", C.c_int32),
-                ("synth_seed", C.c_uint64)]
+                ("synth_seed", C.c_uint64), ("pos_type", C.c_int32), ("ffn_type", C.c_int32)]
 
 
 _lib = None
@@ -299,7 +299,7 @@ class Encoder:
         c.update(cfg or {})
         self.cfg = EncoderCfg(vocab=c["vocab"], hidden=c["hidden"], layers=c["layers"], heads=c["heads"], ffn=c["ffn"],
                               max_pos=c["max_pos"], type_vocab=c["type_vocab"], ln_eps=c["ln_eps"], normalize=1 if normalize else 0,
-                              synth_seed=synth_seed)
+                              synth_seed=synth_seed, pos_type=1 if c.get("alibi") else 0, ffn_type=1 if c.get("geglu") else 0)
         self.rt = rt
         self.hidden = c["hidden"]
         self.max_pos = c["max_pos"]

@@ -47,14 +47,16 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     int pos = tok % S;
     pos = pos >= max_pos ? max_pos - 1 : pos;
     const float* we = wemb + (size_t)id * H;
-    const float* pe = pemb + (size_t)pos * H;
+    const float* pe = pemb ? pemb + (size_t)pos * H : nullptr;  // NULL: no position table (ALiBi models)
     f32x4 v[LN_MAXJ];
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXJ; ++j) {
         const int k0 = 4 * lane + 256 * j;
         if (k0 < H) {
-            v[j] = *reinterpret_cast<const f32x4*>(we + k0) + *reinterpret_cast<const f32x4*>(pe + k0) + *reinterpret_cast<const f32x4*>(temb + k0);
+            v[j] = *reinterpret_cast<const f32x4*>(we + k0);
+            if (pe) v[j] += *reinterpret_cast<const f32x4*>(pe + k0);
+            v[j] += *reinterpret_cast<const f32x4*>(temb + k0);
             sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         }
     }
@@ -142,9 +144,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // One 32-row query block of one wave, keys processed in groups of 4 tiles (128 keys) with an online softmax, so
 // that only 64 score registers are live (S = 256 runs 2 workgroups per CU, S = 512 no longer spills).
 // FULL = every key of the padded sequence is real (len == S): no per-tile guards or masks.
-template <int KT, bool FULL>
+// ALIBI: scores get the symmetric linear bias -slope_head * |query - key| (jina-bert-v2 style encoders, no position table).
+template <int KT, bool FULL, bool ALIBI>
 static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, char* ostg,
-                                                        bf16_t* obase, int H, int len, int nkt, int lane) {
+                                                        bf16_t* obase, int H, int len, int nkt, int lane, int qbase, float slope2) {
     constexpr int GK = KT < 4 ? KT : 4;   // key tiles per group
     constexpr int NG = (KT + GK - 1) / GK;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -173,9 +176,17 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
                 }
+                if (ALIBI) {  // work in the exp2 domain from here on: v = s * sl2 - slope2 * |q - key|
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dist = (float)(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh - (qbase + l31));
+                        acc[r] = fmaf(acc[r], sl2, -slope2 * fabsf(dist));
+                    }
+                }
                 st[i] = acc;
             }
         }
+        const float sc2 = ALIBI ? 1.0f : sl2;  // scores already scaled when ALIBI
         float mx = m_run;
 #pragma unroll
         for (int i = 0; i < GK; ++i) {
@@ -192,8 +203,8 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mb = mx * sl2;
-        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sl2, -mb));  // first group: exp2(-huge) = 0, and O, l are 0 anyway
+        const float mb = mx * sc2;
+        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sc2, -mb));  // first group: exp2(-huge) = 0, and O, l are 0 anyway
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < GK; ++i) {
@@ -202,7 +213,7 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
                 const bool masked = !FULL && (t == nkt - 1) && tail;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(st[i][r], sl2, -mb));
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[i][r], sc2, -mb));
                     if (masked && !(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh < len)) p = 0.f;
                     st[i][r] = p;
                     sum += p;
@@ -283,9 +294,9 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
     }
 }
 
-template <int KT>
+template <int KT, bool ALIBI>
 __global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
-                                                            bf16_t* __restrict__ ctx) {
+                                                            const float* __restrict__ slopes, bf16_t* __restrict__ ctx) {
     constexpr int S = KT * 32;
     constexpr int NQB = (KT + 3) / 4;  // query blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -335,8 +346,9 @@ __global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const
         const int qb = w + 4 * i;
         if (qb < KT) {
             bf16_t* obase = ctx + (size_t)(b * S + qb * 32) * H + head * 64;
-            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane);
-            else attention_qblock<KT, false>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane);
+            const float slope2 = ALIBI ? slopes[head] * 1.44269504088896340736f : 0.f;
+            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true, ALIBI>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
+            else attention_qblock<KT, false, ALIBI>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
         }
     }
 }
@@ -399,28 +411,59 @@ void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab,
 void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s) {
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, s, (const bf16_t*)in, tokens, H, g, b, eps, (bf16_t*)out);
 }
-template <int KT>
-static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, void* ctx, hipStream_t s) {
+template <int KT, bool ALIBI>
+static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, const float* slopes, void* ctx, hipStream_t s) {
     const size_t lds = (size_t)KT * 32 * 256 + 512 + 4 * 2048;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
-    hipLaunchKernelGGL(attention_kernel<KT>, dim3((unsigned)(H / 64), (unsigned)B), dim3(256), lds, s, (const bf16_t*)qkv, lens, H, (bf16_t*)ctx);
+    hipLaunchKernelGGL((attention_kernel<KT, ALIBI>), dim3((unsigned)(H / 64), (unsigned)B), dim3(256), lds, s, (const bf16_t*)qkv, lens, H, slopes,
+                       (bf16_t*)ctx);
 }
 bool sc_attention_supported(int S, int H, int heads) {
     return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512);
 }
-void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, void* ctx, hipStream_t s) {
+// slopes: NULL = plain attention; else [heads] ALiBi slopes (device)
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s) {
+#define SC_ATTN_CASE(SS, KK)                                                      \
+    case SS:                                                                      \
+        if (slopes) launch_attn<KK, true>(qkv, lens, B, H, slopes, ctx, s);      \
+        else launch_attn<KK, false>(qkv, lens, B, H, nullptr, ctx, s);           \
+        break;
     switch (S) {
-        case 32: launch_attn<1>(qkv, lens, B, H, ctx, s); break;
-        case 64: launch_attn<2>(qkv, lens, B, H, ctx, s); break;
-        case 128: launch_attn<4>(qkv, lens, B, H, ctx, s); break;
-        case 256: launch_attn<8>(qkv, lens, B, H, ctx, s); break;
-        case 512: launch_attn<16>(qkv, lens, B, H, ctx, s); break;
+        SC_ATTN_CASE(32, 1)
+        SC_ATTN_CASE(64, 2)
+        SC_ATTN_CASE(128, 4)
+        SC_ATTN_CASE(256, 8)
+        SC_ATTN_CASE(512, 16)
         default: break;
     }
+#undef SC_ATTN_CASE
+}
+// GEGLU (jina-bert-v2 GLUMLP): out[m][j] = gelu(h[m][j]) * h[m][F + j], h = [tokens, 2F] bf16 -> out [tokens, F] bf16
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ h, int64_t tokens, int F, bf16_t* __restrict__ out) {
+    const int64_t total = tokens * (int64_t)(F / 8);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / (F / 8);
+        const int j = (int)(i - m * (F / 8)) * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(h + m * 2 * F + j);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(h + m * 2 * F + F + j);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x2 gg = gelu_erf_fast2(f32x2{bf2f((bf16_t)g[2 * c]), bf2f((bf16_t)g[2 * c + 1])});
+            o[c] = pack_bf16x2(gg[0] * bf2f((bf16_t)u[2 * c]), gg[1] * bf2f((bf16_t)u[2 * c + 1]));
+        }
+        *reinterpret_cast<u32x4*>(out + m * F + j) = o;
+    }
+}
+void sc_launch_geglu(const void* h, int64_t tokens, int F, void* out, hipStream_t s) {
+    int64_t blocks = (tokens * (F / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)h, tokens, F, (bf16_t*)out);
 }
 void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s) {
     hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x, lens, S, H, normalize, out);

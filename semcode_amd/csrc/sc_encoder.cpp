@@ -9,6 +9,7 @@
 //   -> X1 = LN(Y) -> Hm = gelu(X1 W1^T + b1) -> Y2 = Hm W2^T + b2 + X1 -> X = LN(Y2); pooled = masked mean.
 // Activations bf16 in HBM ([tokens, H] row-major, tokens padded to 128), weights bf16 [out, in],
 // biases / LayerNorm parameters / embedding tables f32.
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -23,7 +24,8 @@ void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab,
                         const float* temb, const float* g, const float* b, float eps, void* out, hipStream_t s);
 void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s);
 bool sc_attention_supported(int S, int H, int heads);
-void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, void* ctx, hipStream_t s);
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s);
+void sc_launch_geglu(const void* h, int64_t tokens, int F, void* out, hipStream_t s);
 void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s);
 void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
 void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, float offset, hipStream_t s);
@@ -54,11 +56,12 @@ struct sc_encoder {
     char* params = nullptr;  // one device allocation holding every parameter
     size_t params_bytes = 0;
     float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *embg = nullptr, *embb = nullptr;
+    float* slopes = nullptr;  // ALiBi head slopes (device) or NULL
     std::vector<LayerW> layers;
     // workspace for `ws_tokens` (multiple of 256) tokens
     int64_t ws_tokens = 0;
     char* ws = nullptr;
-    void *x = nullptr, *x1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hm = nullptr;
+    void *x = nullptr, *x1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *hm = nullptr, *hg = nullptr;
     int32_t* ids = nullptr;
     int32_t* lens = nullptr;
     float* pooled = nullptr;
@@ -70,9 +73,9 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // number of f32 values in the weight blob, in blob order (see include/semcode_hip.h)
 static int64_t blob_floats(const sc_encoder_cfg& c) {
-    const int64_t H = c.hidden, F = c.ffn;
-    int64_t n = (int64_t)c.vocab * H + (int64_t)c.max_pos * H + (int64_t)c.type_vocab * H + 2 * H;
-    n += (int64_t)c.layers * (4 * (H * H + H) + 2 * H + (F * H + F) + (H * F + H) + 2 * H);
+    const int64_t H = c.hidden, F = c.ffn, F1 = c.ffn_type == 1 ? 2 * F : F;
+    int64_t n = (int64_t)c.vocab * H + (c.pos_type == 1 ? 0 : (int64_t)c.max_pos * H) + (int64_t)c.type_vocab * H + 2 * H;
+    n += (int64_t)c.layers * (4 * (H * H + H) + 2 * H + (F1 * H + F1) + (H * F + H) + 2 * H);
     return n;
 }
 
@@ -89,6 +92,7 @@ static sc_status check_cfg(const sc_encoder_cfg& c) {
     if (c.hidden % 128 || c.ffn % 128 || c.hidden > 2048)
         return sc_fail(SC_ERR_UNSUPPORTED, "sc_encoder_create: hidden (<=2048) and ffn must be multiples of 128 (got %d, %d)", c.hidden, c.ffn);
     if (!(c.ln_eps > 0.f)) return sc_fail(SC_ERR_INVALID, "sc_encoder_create: ln_eps must be > 0");
+    if (c.pos_type < 0 || c.pos_type > 1 || c.ffn_type < 0 || c.ffn_type > 1) return sc_fail(SC_ERR_INVALID, "sc_encoder_create: unknown pos_type / ffn_type");
     return SC_OK;
 }
 
@@ -106,7 +110,8 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
     if (!e) return sc_fail(SC_ERR_NOMEM, "out of host memory");
     e->rt = rt;
     e->cfg = *cfg;
-    const int64_t H = cfg->hidden, F = cfg->ffn, L = cfg->layers;
+    const int64_t H = cfg->hidden, F = cfg->ffn, L = cfg->layers, F1 = cfg->ffn_type == 1 ? 2 * F : F;
+    const bool alibi = cfg->pos_type == 1;
 
     // staging copy of the f32 blob on device (freed after conversion)
     float* blob = nullptr;
@@ -124,13 +129,14 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
     // parameter arena: f32 tables + per-layer {bf16 matrices, f32 vectors}
     size_t total = 0;
     auto reserve = [&](size_t bytes) { size_t o = total; total += align256(bytes); return o; };
-    const size_t o_wemb = reserve((size_t)cfg->vocab * H * 4), o_pemb = reserve((size_t)cfg->max_pos * H * 4),
+    const size_t o_wemb = reserve((size_t)cfg->vocab * H * 4), o_pemb = reserve(alibi ? 16 : (size_t)cfg->max_pos * H * 4),
+                 o_slopes = reserve((size_t)cfg->heads * 4),
                  o_temb = reserve((size_t)cfg->type_vocab * H * 4), o_eg = reserve(H * 4), o_eb = reserve(H * 4);
     struct LO { size_t wqkv, bqkv, wo, bo, l1g, l1b, w1, b1, w2, b2, l2g, l2b; };
     std::vector<LO> lo(L);
     for (int64_t l = 0; l < L; ++l) {
         lo[l].wqkv = reserve(3 * H * H * 2); lo[l].bqkv = reserve(3 * H * 4); lo[l].wo = reserve(H * H * 2); lo[l].bo = reserve(H * 4);
-        lo[l].l1g = reserve(H * 4); lo[l].l1b = reserve(H * 4); lo[l].w1 = reserve(F * H * 2); lo[l].b1 = reserve(F * 4);
+        lo[l].l1g = reserve(H * 4); lo[l].l1b = reserve(H * 4); lo[l].w1 = reserve(F1 * H * 2); lo[l].b1 = reserve(F1 * 4);
         lo[l].w2 = reserve(H * F * 2); lo[l].b2 = reserve(H * 4); lo[l].l2g = reserve(H * 4); lo[l].l2b = reserve(H * 4);
     }
     he = hipMalloc((void**)&e->params, total);
@@ -161,7 +167,25 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
         return d;
     };
     e->wemb = put_f32(o_wemb, take((int64_t)cfg->vocab * H), (int64_t)cfg->vocab * H, 0);
-    e->pemb = put_f32(o_pemb, take((int64_t)cfg->max_pos * H), (int64_t)cfg->max_pos * H, 0);
+    e->pemb = alibi ? nullptr : put_f32(o_pemb, take((int64_t)cfg->max_pos * H), (int64_t)cfg->max_pos * H, 0);
+    if (alibi) {  // ALiBi head slopes (Press et al.; the non-power-of-two rule of the jina-bert implementation)
+        std::vector<float> sl((size_t)cfg->heads);
+        auto pow2_slopes = [](int n, std::vector<float>& out, int take, int stride) {
+            const double start = std::pow(2.0, -std::pow(2.0, -(std::log2((double)n) - 3.0)));
+            double v = start;
+            for (int i = 0, got = 0; i < n && got < take; ++i, v *= start)
+                if (i % stride == 0) { out.push_back((float)v); ++got; }
+        };
+        std::vector<float> tmp;
+        int p2 = 1;
+        while (p2 * 2 <= cfg->heads) p2 *= 2;
+        pow2_slopes(p2, tmp, p2, 1);
+        if (p2 < cfg->heads) pow2_slopes(2 * p2, tmp, cfg->heads - p2, 2);
+        for (int h = 0; h < cfg->heads; ++h) sl[(size_t)h] = tmp[(size_t)h];
+        e->slopes = (float*)(e->params + o_slopes);
+        hipMemcpyAsync(e->slopes, sl.data(), sl.size() * 4, hipMemcpyHostToDevice, s);
+        hipStreamSynchronize(s);  // sl goes out of scope
+    }
     e->temb = put_f32(o_temb, take((int64_t)cfg->type_vocab * H), (int64_t)cfg->type_vocab * H, 0);
     e->embg = put_f32(o_eg, take(H), H, 1);
     e->embb = put_f32(o_eb, take(H), H, 2);
@@ -184,8 +208,8 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
         w.bo = put_f32(lo[l].bo, take(H), H, 2);
         w.ln1g = put_f32(lo[l].l1g, take(H), H, 1);
         w.ln1b = put_f32(lo[l].l1b, take(H), H, 2);
-        w.w1 = put_bf16(lo[l].w1, take(F * H), F * H);
-        w.b1 = put_f32(lo[l].b1, take(F), F, 2);
+        w.w1 = put_bf16(lo[l].w1, take(F1 * H), F1 * H);
+        w.b1 = put_f32(lo[l].b1, take(F1), F1, 2);
         w.w2 = put_bf16(lo[l].w2, take(H * F), H * F);
         w.b2 = put_f32(lo[l].b2, take(H), H, 2);
         w.ln2g = put_f32(lo[l].l2g, take(H), H, 1);
@@ -217,17 +241,17 @@ static sc_status ensure_ws(sc_encoder* e, int64_t B, int64_t S) {
     e->ws = nullptr;
     e->ws_tokens = 0;
     e->ws_batch = 0;
-    const int64_t H = e->cfg.hidden, F = e->cfg.ffn;
+    const int64_t H = e->cfg.hidden, F = e->cfg.ffn, F1 = e->cfg.ffn_type == 1 ? 2 * F : F;
     const int64_t nb = B > e->ws_batch ? B : e->ws_batch;
     size_t total = 0;
     auto reserve = [&](size_t bytes) { size_t o = total; total += align256(bytes); return o; };
     const size_t ox = reserve(tokens * H * 2), ox1 = reserve(tokens * H * 2), oy = reserve(tokens * H * 2), oqkv = reserve(tokens * 3 * H * 2),
-                 octx = reserve(tokens * H * 2), ohm = reserve(tokens * F * 2), oids = reserve(tokens * 4), olens = reserve(nb * 4),
-                 opool = reserve(nb * H * 4);
+                 octx = reserve(tokens * H * 2), ohm = reserve(tokens * F1 * 2), ohg = reserve(e->cfg.ffn_type == 1 ? tokens * F * 2 : 16),
+                 oids = reserve(tokens * 4), olens = reserve(nb * 4), opool = reserve(nb * H * 4);
     hipError_t he = hipMalloc((void**)&e->ws, total);
     if (he != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc encoder workspace (%zu B) failed: %s", total, hipGetErrorString(he));
     SC_HIP(hipMemsetAsync(e->ws, 0, total, e->rt->stream));  // padded rows must hold finite values
-    e->x = e->ws + ox; e->x1 = e->ws + ox1; e->y = e->ws + oy; e->qkv = e->ws + oqkv; e->ctx = e->ws + octx; e->hm = e->ws + ohm;
+    e->x = e->ws + ox; e->x1 = e->ws + ox1; e->y = e->ws + oy; e->qkv = e->ws + oqkv; e->ctx = e->ws + octx; e->hm = e->ws + ohm; e->hg = e->ws + ohg;
     e->ids = (int32_t*)(e->ws + oids); e->lens = (int32_t*)(e->ws + olens); e->pooled = (float*)(e->ws + opool);
     e->ws_tokens = tokens;
     e->ws_batch = nb;
@@ -251,17 +275,23 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         hipEvent_t a0, a1;
         sc_prof_begin(rt, SC_PROF_ATTN, &a0, &a1);
-        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->ctx, s);
+        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->slopes, e->ctx, s);
         sc_prof_end(rt, SC_PROF_ATTN, a0, a1);
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
         sc_launch_gemm_bf16(EPI_BIAS_RES, e->ctx, H, w.wo, H, w.bo, e->x, H, e->y, H, M, H, H, s);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         sc_launch_layernorm(e->y, tokens, H, w.ln1g, w.ln1b, c.ln_eps, e->x1, s);
+        const void* ffn_in = e->hm;
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s);
+        if (c.ffn_type == 1) sc_launch_gemm_bf16(EPI_BIAS, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, 2 * F, M, 2 * F, H, s);
+        else sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        if (c.ffn_type == 1) {  // GEGLU: gelu(gate) * up
+            sc_launch_geglu(e->hm, M, F, e->hg, s);
+            ffn_in = e->hg;
+        }
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS_RES, e->hm, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, ffn_in, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         sc_launch_layernorm(e->y, tokens, H, w.ln2g, w.ln2b, c.ln_eps, e->x, s);
     }
@@ -275,7 +305,7 @@ static sc_status check_embed_args(sc_encoder* e, const void* ids, const void* le
     if (B < 1 || B > 65536) return sc_fail(SC_ERR_INVALID, "embed: batch %d out of range", B);
     if (!sc_attention_supported(S, e->cfg.hidden, e->cfg.heads))
         return sc_fail(SC_ERR_UNSUPPORTED, "embed: sequence length %d not in {32,64,128,256,512} (pad on the host)", S);
-    if (S > e->cfg.max_pos) return sc_fail(SC_ERR_INVALID, "embed: sequence length %d exceeds max_pos %d", S, e->cfg.max_pos);
+    if (S > e->cfg.max_pos && e->cfg.pos_type == 0) return sc_fail(SC_ERR_INVALID, "embed: sequence length %d exceeds max_pos %d", S, e->cfg.max_pos);
     return SC_OK;
 }
 
@@ -370,7 +400,7 @@ extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const i
     if (dl.alloc((size_t)B * 4) != hipSuccess || dc.alloc((size_t)tokens * H * 2) != hipSuccess || fo.alloc((size_t)tokens * H * 4) != hipSuccess)
         return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
     SC_HIP(hipMemcpyAsync(dl.p, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    sc_launch_attention(dq.p, (const int32_t*)dl.p, B, S, H, dc.p, s);
+    sc_launch_attention(dq.p, (const int32_t*)dl.p, B, S, H, nullptr, dc.p, s);
     sc_launch_bf16_to_f32(dc.p, (float*)fo.p, tokens * H, s);
     SC_HIP(hipGetLastError());
     SC_HIP(hipMemcpyAsync(out, fo.p, (size_t)tokens * H * 4, hipMemcpyDeviceToHost, s));

@@ -145,3 +145,29 @@ def test_encoder_bad_arguments(rt):
     with pytest.raises(_native.ScError):
         enc.embed_ids(np.zeros((1, 128), np.int32), np.ones(1, np.int32))  # S > max_pos
     enc.close()
+
+
+@pytest.mark.parametrize("switches", [dict(alibi=True), dict(geglu=True), dict(alibi=True, geglu=True)])
+def test_jina_v2_switches_match_restatement(rt, switches):
+    """ALiBi attention bias and GEGLU feed-forward (jina-embeddings-v2 family).  No independent implementation exists
+    offline for these switches: parity is against this repo's own numpy restatement only."""
+    cfg = dict(bo.BERT_BASE, vocab=400, hidden=256, layers=2, heads=4, ffn=512, max_pos=64, **switches)
+    blob = bo.make_blob(cfg, 11, "test")
+    enc = _native.Encoder(rt, cfg, weights=blob)
+    rng = np.random.default_rng(3)
+    for S in (32, 256) if switches.get("alibi") else (32, 64):
+        ids = rng.integers(1, 400, size=(5, S)).astype(np.int32)
+        lens = np.array([S, S // 2 + 1, 3, S - 1, 17], np.int32)
+        check_pooled(enc.embed_ids(ids, lens), bo.forward(cfg, blob, ids, lens))
+    enc.close()
+
+
+def test_jina_v2_base_shape(rt):
+    cfg = dict(bo.BERT_BASE, layers=2, alibi=True, geglu=True)  # 12 heads: non-power-of-two slope ladder
+    blob = bo.make_blob(cfg, 12, "test")
+    enc = _native.Encoder(rt, cfg, weights=blob)
+    rng = np.random.default_rng(4)
+    ids = rng.integers(1, 30000, size=(3, 128)).astype(np.int32)
+    lens = np.array([128, 77, 40], np.int32)
+    check_pooled(enc.embed_ids(ids, lens), bo.forward(cfg, blob, ids, lens))
+    enc.close()
