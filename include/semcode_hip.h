@@ -155,6 +155,10 @@ sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const f
  * the product kernel, other values = diagnostic ablations whose outputs are meaningless). */
 sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant,
                              double* ms_per_launch);
+/* cap_words / (8 * tiles) back-to-back traced launches of the 256x256-tile GEMM (M, N multiples of 256): out[launch][tile][8] =
+ * {0: HW_ID, 1: XCC_ID, 2: entry, 3: main loop done, 4: epilogue issued, 5: stores drained}, stamps in 10 ns wall-clock
+ * ticks.  Kernel tuning aid (scripts/gemm_trace.py). */
+sc_status sc_diag_gemm_trace(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* out, int64_t cap_words);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
 sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sc_tokenizer_encode": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "sc_diag_gemm_trace": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "sc_index_destroy": (C.c_int32, [C.c_void_p]),
@@ -407,6 +408,14 @@ def diag_gemm_bench(rt: Runtime, M: int, N: int, K: int, epi: int = 0, iters: in
     ms = C.c_double()
     _check(lib().sc_diag_gemm_bench(rt.handle, epi, M, N, K, iters, variant, C.byref(ms)))
     return ms.value
+
+
+def diag_gemm_trace(rt: Runtime, M: int, N: int, K: int, epi: int = 0, launches: int = 1) -> np.ndarray:
+    """Per-workgroup time stamps of back-to-back 256-tile GEMM launches: [launches, ntiles, 8] uint64 (see include/semcode_hip.h)."""
+    nt = (M // 256) * (N // 256)
+    out = np.zeros((launches, nt, 8), np.uint64)
+    _check(lib().sc_diag_gemm_trace(rt.handle, epi, M, N, K, out.ctypes.data_as(C.c_void_p), out.size))
+    return out
 
 
 def diag_attention(rt: Runtime, qkv, lens, B: int, S: int, heads: int) -> np.ndarray:

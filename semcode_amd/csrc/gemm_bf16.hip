@@ -34,6 +34,7 @@ struct GemmArgs {
     int tiles_n;       // N / 128
     int ntiles;        // (M/128) * tiles_n
     int order;         // 256-tile kernels: tile walk (see gemm256_tile)
+    unsigned long long* trace;  // diagnostic: per-workgroup time stamps [ntiles][8] (sc_diag_gemm_trace), else nullptr
 };
 
 template <int EPI>
@@ -84,111 +85,148 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 
 
 // ---- 256 x 256 x 64 tile variant (gemm_tile.h, second half); used when M % 256 == 0 and N % 256 == 0.
-// PERSIST: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the (fire-and-forget) epilogue stores of
-// one tile drain while the LDS-DMA of the next tile is already in flight.  The K loop is register-tight (256
-// VGPRs), so everything the epilogue needs per lane is re-derived after the loop from an opaque copy of the lane id;
-// otherwise hipcc hoists that address arithmetic above the K loop and spills inside it.
-template <int EPI, int DBG>
-static __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, int vt, char* smem, int w, int lane) {
-    const int wm = w >> 2, wn = w & 3;
-    constexpr int STG_ROW = 64 * 4 + 16;  // bytes: 64 f32 + 16 B pad (conflict-free b128 writes)
-    {
-        // tile order: bit 0 of a.order = skip the XCD remap; a.order >> 1 = G: walk column-major inside groups of G row panels
-        const int tile = (a.order & 1) ? vt : xcd_remap(vt, a.ntiles);
-        int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-        const int G = a.order >> 1;
-        if (G > 1) {
-            const int tiles_m = a.ntiles / a.tiles_n;
-            const int gsz = G * a.tiles_n, g = tile / gsz, r = tile - g * gsz;
-            const int rows_here = (g * G + G <= tiles_m) ? G : tiles_m - g * G;  // last group may be short
-            mt = g * G + r % rows_here;
-            nt = r / rows_here;
-        }
-        const int m0 = __builtin_amdgcn_readfirstlane(mt * T_BM), n0 = __builtin_amdgcn_readfirstlane(nt * T_BN);
+// tile walk: bit 0 of order = skip the XCD remap; order >> 1 = G: walk column-major inside groups of G row panels
+static __device__ __forceinline__ void tile_coords256(const GemmArgs& a, int vt, int& m0, int& n0) {
+    const int tile = (a.order & 1) ? vt : xcd_remap(vt, a.ntiles);
+    int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int G = a.order >> 1;
+    if (G > 1) {
+        const int tiles_m = a.ntiles / a.tiles_n;
+        const int gsz = G * a.tiles_n, g = tile / gsz, r = tile - g * gsz;
+        const int rows_here = (g * G + G <= tiles_m) ? G : tiles_m - g * G;  // last group may be short
+        mt = g * G + r % rows_here;
+        nt = r / rows_here;
+    }
+    m0 = __builtin_amdgcn_readfirstlane(mt * T_BM);
+    n0 = __builtin_amdgcn_readfirstlane(nt * T_BN);
+}
 
-        f32x4 acc[4][8];  // [ni][mi]
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_tile256_mainloop<DBG & 3>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
-        if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
-            float sink = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
-            if (sink == 12345.678f) a.C[0] = 1;
-            return;
-        }
-        // ---- epilogue through LDS: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row
-        // segments per store instruction); staging the wave's 128 x 64 f32 block in 4 passes of 32 rows lets it
-        // leave as whole 128-byte row segments, 16 B per lane.  The pipeline buffers are free here: after the
-        // main loop's last barrier no wave reads them again.  Staging is wave-private (LDS executes a wave's
-        // instructions in order), so no barrier is needed inside the epilogue.
+// Residual tile -> LDS.  After the last barrier of the main loop the 128 KiB of pipeline buffers are dead, exactly the size of
+// the 256 x 256 bf16 residual tile: every wave LDS-DMAs its own 128 x 64 part (16 pieces of 1 KiB = 8 rows x 128 B each)
+// into its own 16 KiB, under the final 32 MFMAs and at no register cost.  Rows are 128 B; the 16-byte chunk c of row r
+// sits at chunk c ^ ((r >> 1) & 7) (applied on the source address, LDS-DMA writes linearly), which makes the epilogue's
+// 8-byte reads in the MFMA layout bank-conflict free.  Fetched from registers block by block next to the stores, the
+// residual cost a full load + store round trip per block: 12 us per tile against a 20 us main loop
+// (profiles/r1o_gemm_trace.log).
+struct ResidualTailHook {
+    const bf16_t* R;  // tile origin: R + m0 * ldr + n0
+    int ldr, w, lane;
+    char* smem;
+    __device__ __forceinline__ void operator()() const {
         int ln = lane;
-        asm volatile("" : "+v"(ln));  // opaque: nothing below can be computed before the K loop
-        __builtin_amdgcn_sched_barrier(0);
-        const int fr = ln & 15, fq = ln >> 4;
-        const int prow = ln >> 3, c8 = (ln & 7) * 8;
-        char* stg = smem + w * (32 * STG_ROW);
-        f32x4 bias4[4];
+        asm volatile("" : "+v"(ln));  // keep the address arithmetic out of the register-tight K loop
+        const int wm = w >> 2, wn = w & 3;
+        const int prow = ln >> 3, pos = ln & 7;
+        char* dst = smem + w * 16384;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+        for (int d = 0; d < 16; ++d) {
+            const int row = d * 8 + prow;
+            const int cs = pos ^ ((row >> 1) & 7);
+            const bf16_t* g = R + (size_t)(wm * 128 + row) * ldr + wn * 64 + cs * 8;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(dst + d * 1024), 16, 0, 0);
+        }
+    }
+};
+
+// Epilogue: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row segments per store).  Each
+// wave stages one 16-row x 64-column block at a time as bf16 in its private LDS slice BEHIND the pipeline buffers and
+// stores whole 128-byte row segments, 16 B per lane.  bias, GELU and the residual (read from LDS, see above) are applied
+// in f32 before the single bf16 rounding.  DS operations of one wave execute in order, so the slice is reused without
+// waits beyond the data dependencies.  Everything per lane is derived from an opaque copy of the lane id so that hipcc
+// cannot hoist it above the register-tight K loop.
+template <int EPI>
+static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m0, int n0, char* smem, int w, int lane, f32x4 (&acc)[4][8]) {
+    const int wm = w >> 2, wn = w & 3;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    __builtin_amdgcn_sched_barrier(0);
+    const int fr = ln & 15, fq = ln >> 4;
+    const int prow = ln >> 3, c8 = (ln & 7) * 8;
+    char* stg = smem + 4 * T_TILE_BYTES + w * (16 * T_EPI_ROW);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 bias4[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+    for (int ni = 0; ni < 4; ++ni) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+    const char* rlds = smem + w * 16384 + fr * 128 + (fq & 1) * 8;  // + mi * 2048 + ((chunk ^ swz) << 4)
+    const int swz = (fr >> 1) & 7;                                  // ((mi * 16 + fr) >> 1) & 7
+    u32x2 rr[8][4];  // residual in the MFMA layout, read up front (the fragment registers are dead): the compiler cannot
+                     // move LDS reads across the staging writes below, and one read -> add -> write chain per block is slow
+    if (EPI == EPI_BIAS_RES) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's residual DMA has landed
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    f32x4 v = acc[ni][2 * p + h] + bias4[ni];
-                    if (EPI == EPI_BIAS_GELU) {
-                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
-                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                    }
-                    *reinterpret_cast<f32x4*>(stg + (h * 16 + fr) * STG_ROW + (ni * 16 + 4 * fq) * 4) = v;
-                }
+            for (int ni = 0; ni < 4; ++ni)
+                rr[mi][ni] = *reinterpret_cast<const u32x2*>(rlds + mi * 2048 + (((ni * 2 + (fq >> 1)) ^ swz) << 4));
+    }
+    bf16_t* cp = a.C + (size_t)(m0 + wm * 128 + prow) * a.ldc + n0 + wn * 64 + c8;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rl = j * 8 + prow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + rl * STG_ROW + c8 * 4 + 16);
-                const size_t m = (size_t)(m0 + wm * 128 + p * 32 + rl);
-                const int n = n0 + wn * 64 + c8;
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                if (EPI == EPI_BIAS_RES) {
-                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.R + m * a.ldr + n);
+    for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += bf16_to_f32((bf16_t)rv[r]);
-                }
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
-                *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = o;
+        for (int ni = 0; ni < 4; ++ni) {
+            f32x4 v = acc[ni][mi] + bias4[ni];
+            if (EPI == EPI_BIAS_GELU) {
+                const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                v = f32x4{g0[0], g0[1], g1[0], g1[1]};
             }
+            if (EPI == EPI_BIAS_RES) {
+                const u32x2 r2 = rr[mi][ni];
+                v += f32x4{__builtin_bit_cast(float, r2[0] << 16), __builtin_bit_cast(float, r2[0] & 0xFFFF0000u),
+                           __builtin_bit_cast(float, r2[1] << 16), __builtin_bit_cast(float, r2[1] & 0xFFFF0000u)};
+            }
+            *reinterpret_cast<u32x2*>(stg + fr * T_EPI_ROW + (ni * 16 + 4 * fq) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg + (j * 8 + prow) * T_EPI_ROW + c8 * 2);
+            *reinterpret_cast<u32x4*>(cp + (size_t)(mi * 16 + j * 8) * a.ldc) = o;
         }
     }
 }
 
-template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    gemm256_tile<EPI, DBG>(a, blockIdx.x, smem, w, lane);
+// diagnostic time stamps (100 MHz wall clock): slot 0 = HW_ID, 1 = XCC_ID, 2.. = stamps
+static __device__ __forceinline__ void gemm256_stamp(const GemmArgs& a, int tile, int slot) {
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)tile * 8 + slot] = (unsigned long long)wall_clock64();
 }
 
-// one workgroup per CU walking tiles blockIdx.x, + gridDim.x, ...
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_persistent_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB pipeline buffers + epilogue staging
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll 1
-    for (int vt = blockIdx.x; vt < a.ntiles; vt += gridDim.x) {
-        if (vt != (int)blockIdx.x) __syncthreads();  // every wave is done reading its epilogue staging of the previous tile
-        gemm256_tile<EPI, 0>(a, vt, smem, w, lane);
+    if (a.trace && threadIdx.x == 0) {
+        a.trace[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+        a.trace[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    }
+    gemm256_stamp(a, blockIdx.x, 2);
+    int m0, n0;
+    tile_coords256(a, blockIdx.x, m0, n0);
+    f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS_RES && !DBG)
+        gemm_tile256_mainloop<0>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
+                                 ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem});
+    else
+        gemm_tile256_mainloop<(DBG & 3) | ((DBG & 16) ? 4 : 0)>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
+    gemm256_stamp(a, blockIdx.x, 3);
+    if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
+        if (sink == 12345.678f) a.C[0] = 1;
+        return;
+    }
+    gemm256_epilogue<EPI>(a, m0, n0, smem, w, lane, acc);
+    if (a.trace) {
+        gemm256_stamp(a, blockIdx.x, 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gemm256_stamp(a, blockIdx.x, 5);
     }
 }
 
@@ -197,9 +235,10 @@ bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 
 
 static int g_gemm_order = 16;  // XCD remap + column-major walk inside groups of 8 row panels (profiles/r1n_gemm_tile_order.log)
 void sc_gemm_set_order(int v) { g_gemm_order = v; }
+static unsigned long long* g_gemm_trace = nullptr;
+void sc_gemm_set_trace(unsigned long long* dev) { g_gemm_trace = dev; }
 static int g_gemm_dbg = 0;
-static bool g_gemm_persist = false, g_gemm_nopersist = false;
-void sc_gemm_set_debug(int v) { g_gemm_persist = (v == 8); g_gemm_nopersist = (v == 9); g_gemm_dbg = (v == 8 || v == 9) ? 0 : v; }
+void sc_gemm_set_debug(int v) { g_gemm_dbg = v; }
 static bool g_force_tile128 = false;
 void sc_gemm_force_tile128(bool on) { g_force_tile128 = on; }
 
@@ -210,11 +249,12 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
     static const char* env_order = getenv("SC_GEMM_ORDER");  // A/B experiments
     a.order = env_order ? atoi(env_order) : g_gemm_order;
+    a.trace = g_gemm_trace;
     static bool attr_done = false;
     if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
         a.tiles_n = N / T_BN;
         a.ntiles = (M / T_BM) * a.tiles_n;
-        const size_t lds256 = 4 * T_TILE_BYTES;  // 128 KiB
+        const size_t lds256 = T_LDS_BYTES;  // 128 KiB pipeline + 18 KiB epilogue staging
         static bool attr256 = false;
         if (!attr256) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
@@ -230,36 +270,16 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
 
                 attrd = true;
             }
             if (g_gemm_dbg == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 1>), grid, block, lds256, s, a);
             else if (g_gemm_dbg == 2) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 2>), grid, block, lds256, s, a);
             else if (g_gemm_dbg == 4) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 4>), grid, block, lds256, s, a);
+            else if (g_gemm_dbg == 21) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 21>), grid, block, lds256, s, a);
 
             else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 5>), grid, block, lds256, s, a);
-            return;
-        }
-        // The persistent walk (one workgroup per CU) is kept for experiments only (SC_GEMM_PERSIST=1): in the isolated
-        // microbench it wins 7-17 % on the GELU / residual epilogues (profiles/r1m_gemm_microbench.log), but inside the
-        // encoder pipeline, A/B on one device, it loses 6 % end to end (16.95k -> 15.97k chunks/s).
-        static const bool env_persist = getenv("SC_GEMM_PERSIST") != nullptr;
-        if (g_gemm_persist || env_persist) {
-            static int n_cus = 0;
-            static bool attrp = false;
-            if (!attrp) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persistent_kernel<EPI_BIAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                attrp = true;
-            }
-            dim3 pgrid((unsigned)(a.ntiles < n_cus ? a.ntiles : n_cus));
-            if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS_GELU>), pgrid, block, lds256, s, a);
-            else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS_RES>), pgrid, block, lds256, s, a);
-            else hipLaunchKernelGGL((gemm256_persistent_kernel<EPI_BIAS>), pgrid, block, lds256, s, a);
             return;
         }
         if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_GELU>, grid, block, lds256, s, a);

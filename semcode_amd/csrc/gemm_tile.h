@@ -35,22 +35,27 @@ static __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
 }
 
-// two GELUs at once with packed f32 math (v_pk_fma_f32 / v_pk_mul_f32); used in GEMM epilogues, where no MFMA competes
+// two erf-GELUs at once with packed f32 math (v_pk_fma_f32 / v_pk_mul_f32); used in the GEMM epilogues, where the
+// vector ALU is the bound (two waves per SIMD, 128 values per lane each): measured 6 us per 256x256 tile for the
+// A&S 7.1.26 form (16 packed ops + 2 rcp + 2 exp per pair, profiles/r1o_gemm_trace.log).  This form needs 10 packed ops
+// and one exp2 per value:
+//     gelu(x) = max(x, 0) - |h| erfc(sqrt2 |h|),  h = x / 2,     erfc(sqrt2 y) = 2^Q(y)
+// with Q a degree-7 fit of log2 erfc(sqrt2 y) on [0, 6] weighted by the sensitivity y erfc of the result (so the
+// tails are relatively accurate too) and monotonically decreasing beyond the fit range (2^Q -> 0, no clamp needed).
+// Evaluated in f32: |error| <= 2.5e-7 everywhere (the f32 rounding of the sum), <= 0.015 bf16 ulp wherever |gelu| > 1e-3 and <= 0.14 ulp down to 1e-5;
+// tests/test_encoder_gpu.py::test_gelu_epilogue_accuracy checks it through the kernel.
 static __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-    const f32x2 z = ax * 0.70710678118654752440f;
-    const f32x2 den = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
-    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-    f32x2 p = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){0.254829592f, 0.254829592f});
-    const f32x2 zz = z * z * -1.44269504088896340736f;
-    const f32x2 ex = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
-    const f32x2 e = p * t * ex;                       // 1 - erf(z)
-    const f32x2 h = x * 0.5f;                         // gelu = h * (1 + sign(x) * (1 - e)) = h + |h| * (1 - e) ... by sign
-    const f32x2 ah = ax * 0.5f;
-    return h + (ah - ah * e);                         // x>=0: h + h(1-e) ; x<0: h - |h|... = h + |h|(1-e)  (since h = -|h|)
+    const f32x2 h = x * 0.5f;
+    const f32x2 ah = {fabsf(h[0]), fabsf(h[1])};
+    f32x2 q = __builtin_elementwise_fma(ah, (f32x2){-0.000139362935f, -0.000139362935f}, (f32x2){0.00303643686f, 0.00303643686f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){-0.0268522501f, -0.0268522501f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){0.131913051f, 0.131913051f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){-0.428876668f, -0.428876668f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){-1.83460581f, -1.83460581f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){-2.30246782f, -2.30246782f});
+    q = __builtin_elementwise_fma(q, ah, (f32x2){9.69476332e-06f, 9.69476332e-06f});
+    const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    return __builtin_elementwise_fma(-ah, e, h + ah);
 }
 
 static __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
@@ -147,6 +152,10 @@ static __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 #define T_BM 256
 #define T_BN 256
 #define T_TILE_BYTES (256 * 64 * 2)  // 32 KiB per operand tile
+#define T_EPI_ROW 144                // epilogue staging row: 64 bf16 + 16 B pad
+#define T_EPI_BYTES (8 * 16 * T_EPI_ROW)  // 8 waves x 16 rows, placed BEHIND the 128 KiB pipeline buffers
+#define T_LDS_BYTES (4 * T_TILE_BYTES + T_EPI_BYTES)
+
 
 static __device__ __forceinline__ void stage_tile256(const bf16_t* __restrict__ src, int ld, int row0, int k0, char* lds_tile, int w, int lane) {
 #pragma unroll
@@ -187,10 +196,18 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 
 // acc[ni][mi][r] = sum_k A[m0 + wm*128 + mi*16 + (lane&15)][k] * W[n0 + wn*64 + ni*16 + 4*(lane>>4) + r][k]
 // smem: 128 KiB ([2][A tile | W tile]).  All 512 threads of the workgroup must call it.  K % 64 == 0.
-// DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs.
-template <int DBG = 0>
+// DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs, bit 2 = skip the fragment reads
+// (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).
+// tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
+// reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
+// tile, gemm_bf16.hip) and have it land under those MFMAs.
+struct NoTailHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int DBG = 0, class TailHook = NoTailHook>
 static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
-                                                              int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane) {
+                                                              int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
+                                                              TailHook tail = TailHook{}) {
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
@@ -206,6 +223,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
     __syncthreads();
     Frag256 f0, f1;
     read_frags256(smem, smem + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
+    if (DBG & 4) read_frags256(smem, smem + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
     // One K-tile.  STAGE: a tile kt+2 exists and is requested; NEXT: a tile kt+1 exists and its k-step-0
     // fragments are fetched.  sched_barrier(0) pins the order hipcc would otherwise relax (it sinks the
     // register-only MFMAs below the barrier and the LDS-DMA issue below the next MFMA block, which halves
@@ -214,20 +232,39 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
         constexpr bool STAGE = decltype(stage_c)::value, NEXT = decltype(next_c)::value;
         char* cur = smem + (kt & 1) * (2 * T_TILE_BYTES);
         char* nxt = smem + ((kt + 1) & 1) * (2 * T_TILE_BYTES);
-        read_frags256(cur, cur + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
+        if (!(DBG & 4)) read_frags256(cur, cur + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
         if (!(DBG & 2)) mfma_frags256(f0, acc);
         else asm volatile("" ::"v"(f0.wf[0]), "v"(f0.af[0]), "v"(f0.wf[3]), "v"(f0.af[7]));
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my LDS-DMA of tile kt+1 (issued one K-tile ago)
         __syncthreads();                                   // + every wave's reads of `cur` are complete
+        if (!STAGE && !NEXT) tail();
         if (STAGE && !(DBG & 1)) {
             stage_tile256(A, lda, m0, (kt + 2) * G_BK, cur, w, lane);
             stage_tile256(W, ldw, n0, (kt + 2) * G_BK, cur + T_TILE_BYTES, w, lane);
         }
-        if (NEXT) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (NEXT && !(DBG & 4)) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
         if (!(DBG & 2)) mfma_frags256(f1, acc);
         else asm volatile("" ::"v"(f1.wf[0]), "v"(f1.af[0]), "v"(f1.wf[3]), "v"(f1.af[7]));
+        if (STAGE && !(DBG & 1) && NEXT && !(DBG & 2) && !(DBG & 4)) {
+            // spread the 8 LDS-DMA issues (each ~100 issue cycles with its address arithmetic) and the 12 fragment reads
+            // between the 32 MFMAs instead of bursting them right after the barrier, where both waves of a SIMD would
+            // stall the matrix pipe together: groups of {1 VMEM, 1-2 DS reads, 4 MFMA}
+#define SC_SGB3(NDS)                                        \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   /* VMEM (LDS-DMA) */ \
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS read */        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   /* MFMA */
+            SC_SGB3(2) SC_SGB3(2) SC_SGB3(2) SC_SGB3(2) SC_SGB3(1) SC_SGB3(1) SC_SGB3(1) SC_SGB3(1)
+#undef SC_SGB3
+        }
+        if (!STAGE && !NEXT && !std::is_same<TailHook, NoTailHook>::value && !DBG) {
+            // the tail hook's 16 LDS-DMA issues, spread over the last 32 MFMAs the same way
+#define SC_SGB2                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); /* VMEM (LDS-DMA) */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); /* MFMA */
+            SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2 SC_SGB2
+#undef SC_SGB2
+        }
     };
     using T = std::true_type;
     using F = std::false_type;

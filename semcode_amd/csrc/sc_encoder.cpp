@@ -33,6 +33,7 @@ void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s)
 
 void sc_gemm_set_debug(int v);
 void sc_gemm_set_order(int v);
+void sc_gemm_set_trace(unsigned long long* dev);
 void sc_gemm_force_tile128(bool on);
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
@@ -411,6 +412,39 @@ extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const i
 // Time `iters` launches of one GEMM shape on device-resident synthetic bf16 data (hipEvents on the
 // runtime's stream).  variant: 0 = product kernel; 1/2/4/5 = diagnostic ablations of the 256-tile kernel
 // (no in-loop LDS-DMA / no MFMA / no epilogue / no DMA + no epilogue); 128 = force the 128x128 tile.
+extern "C" sc_status sc_diag_gemm_trace(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* out, int64_t cap_words) {
+    if (!rt || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_trace: bad argument");
+    if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % 64)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_trace: need M%%256==0, N%%256==0, K%%64==0");
+    const int64_t ntiles = (int64_t)(M / 256) * (N / 256);
+    const int64_t launches = cap_words / (ntiles * 8);  // back-to-back traced launches, [launch][tile][8]
+    if (launches < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_trace: out too small (need 8 words per tile)");
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    DevBuf fa, da, fw, dw, db, dr, dc, tr;
+    const int64_t na = (int64_t)M * K, nw = (int64_t)N * K, nc = (int64_t)M * N;
+    const size_t trace_bytes = (size_t)launches * ntiles * 64;
+    if (fa.alloc(na * 4) != hipSuccess || da.alloc(na * 2) != hipSuccess || fw.alloc(nw * 4) != hipSuccess || dw.alloc(nw * 2) != hipSuccess ||
+        db.alloc((size_t)N * 4) != hipSuccess || dr.alloc(nc * 2) != hipSuccess || dc.alloc(nc * 2) != hipSuccess || tr.alloc(trace_bytes) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    sc_launch_synth_scaled((float*)fa.p, na, 1, 1.0f, 0.0f, s);
+    sc_launch_synth_scaled((float*)fw.p, nw, 2, 0.05f, 0.0f, s);
+    sc_launch_f32_to_bf16((const float*)fa.p, da.p, na, s);
+    sc_launch_f32_to_bf16((const float*)fw.p, dw.p, nw, s);
+    SC_HIP(hipMemsetAsync(db.p, 0, (size_t)N * 4, s));
+    SC_HIP(hipMemsetAsync(dr.p, 0, (size_t)nc * 2, s));
+    SC_HIP(hipMemsetAsync(tr.p, 0, trace_bytes, s));
+    for (int i = 0; i < 2; ++i) sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    for (int64_t l = 0; l < launches; ++l) {
+        sc_gemm_set_trace((unsigned long long*)tr.p + l * ntiles * 8);
+        sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    }
+    sc_gemm_set_trace(nullptr);
+    hipError_t he = hipStreamSynchronize(s);
+    if (he != hipSuccess) return sc_fail(SC_ERR_HIP, "diag gemm trace failed: %s", hipGetErrorString(he));
+    SC_HIP(hipMemcpy(out, tr.p, trace_bytes, hipMemcpyDeviceToHost));
+    return SC_OK;
+}
+
 extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant,
                                         double* ms_per_launch) {
     if (!rt || !ms_per_launch || iters < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bench: bad argument");

@@ -30,6 +30,27 @@ def gelu(x):
     return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
 
 
+def test_gelu_epilogue_accuracy(rt):
+    """The 256-tile GEMM's GELU epilogue on its own: W = identity passes bf16 inputs through the accumulator unchanged, so
+    out = bf16(gelu(x)) for x over [-16, 16] including both tails.  Bar: within one bf16 rounding of the erf definition
+    (half an ulp) plus the approximation error of gemm_tile.h gelu_erf_fast2 -- 0.015 ulp wherever |gelu| > 1e-3, 0.14 ulp
+    down to |gelu| > 1e-5 -- and 1e-6 absolute below that."""
+    M = N = K = 256
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.linspace(-16.0, 16.0, M * K // 2), rng.standard_normal(M * K // 2) * 2.0]).astype(np.float32)
+    A = bf16_round(x.reshape(M, K))
+    W = np.eye(N, K, dtype=np.float32)
+    got = _native.diag_gemm_bf16(rt, A, W, np.zeros(N, np.float32), None, epi=1).astype(np.float64)
+    ref = gelu(A.astype(np.float64))
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-300))) - 7)
+    err = np.abs(got - ref)
+    big, mid = np.abs(ref) > 1e-5, np.abs(ref) > 1e-3
+    assert (err[mid] / ulp[mid]).max() <= 0.515, (err[mid] / ulp[mid]).max()
+    assert (err[big] / ulp[big]).max() <= 0.64, (err[big] / ulp[big]).max()
+    assert err[~big].max() <= 1e-6, err[~big].max()
+    assert np.all(got[A > 12] == A[A > 12]) and np.all(np.abs(got[A < -12]) < 1e-30)  # saturated tails, no NaN
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 768, 3072),  # 128x128 tiles
                                    (256, 256, 64), (256, 256, 128), (512, 768, 768), (256, 768, 3072), (1024, 2304, 192)])  # 256x256 tiles
