@@ -131,6 +131,13 @@ sc_status sc_encoder_embed_ids(sc_encoder* enc, const int32_t* ids, const int32_
 sc_status sc_encoder_embed_ids_dev(sc_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S,
                                    float* out_dev);
 
+/* embed_documents + upsert of one batch (indexer.py:150 -> milvus_store.py:128) without leaving the device: the
+ * pooled vectors go straight from the encoder's output buffer into index rows `rows` (semantics of
+ * sc_index_put_rows).  out may be NULL; if not, the vectors are also copied to the host [B,hidden].  Encoder and
+ * index must belong to the same runtime and hidden == dim.  Host pointers; synchronises. */
+sc_status sc_encoder_embed_ids_into(sc_encoder* enc, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, sc_index* ix,
+                                    const int64_t* rows, float* out);
+
 /* ----------------------------------------------------------------- tokenizer ---- */
 typedef struct sc_tokenizer sc_tokenizer;
 /* Host-side WordPiece tokenizer (BERT scheme), the step the reference leaves to its provider's library (raw strings
@@ -179,6 +186,13 @@ sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n);
 /* Replace existing rows: rows[i] (local row number) <- vecs[i].  The replace-by-primary-key half
  * of Collection.upsert (milvus_store.py:128); the md5 -> row map lives in Python. */
 sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n);
+/* Upsert in one call: rows[i] <- vecs[i] where rows[i] is either an existing row (replace) or the next free row
+ * (append; new rows must be numbered old_rows, old_rows+1, ... in the order they appear).  Row numbers must be
+ * distinct.  One Collection.upsert batch (milvus_store.py:119-130) without the add/overwrite split. */
+sc_status sc_index_put_rows(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n);
+/* Same with vecs a DEVICE pointer ([n,dim] f32, tight); rows stays a host pointer.  Asynchronous on the runtime's
+ * stream: the embed -> store hand-over without a trip through host memory. */
+sc_status sc_index_put_rows_dev(sc_index* ix, const float* vecs_dev, const int64_t* rows, int64_t n);
 /* Copy rows [first, first+n) back to the host as [n,dim] (persistence, tests). */
 sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, float* out);
 /* Resize to n rows and fill them on device with sc_synth_fill_dev(seed, first_row). */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sc_encoder_info": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg)]),
     "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_encoder_embed_ids_into": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]),
     "sc_tokenizer_destroy": (C.c_int32, [C.c_void_p]),
     "sc_tokenizer_info": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 5),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "sc_index_reserve": (C.c_int32, [C.c_void_p, C.c_int64]),
     "sc_index_add": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     "sc_index_overwrite": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "sc_index_put_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "sc_index_put_rows_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "sc_index_get_rows": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "sc_index_fill_synthetic": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
     "sc_index_fill_synthetic_clustered": (C.c_int32, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_float]),
@@ -102,6 +105,15 @@ def lib() -> C.CDLL:
                     f"{LIB_PATH} is missing: build it with `python -m semcode_amd.csrc.build` "
                     "(needs hipcc); semcode_amd has no CPU fallback."
                 )
+            # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 under the system library's sonames, and the
+            # copy that is loaded first serves the whole process.  With ours first, a later torch.cuda call in the same
+            # process (torch.distributed in bench.py / storage.sharded, device tensors handed to the *_dev entry points)
+            # fails with "No HIP GPUs are available"; so where torch is installed it is loaded first.  The library itself
+            # never calls into torch.
+            try:
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover - torch is optional for the library
+                pass
             handle = C.CDLL(str(LIB_PATH))
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
@@ -179,6 +191,22 @@ class Runtime:
         _check(lib().sc_synth_fill_dev(self.handle, C.c_void_p(dev_ptr), rows, dim, ld, seed, first_row))
 
 
+_shared_runtimes: dict = {}
+_shared_lock = threading.Lock()  # not _lib_lock: Runtime() takes that one inside lib()
+
+
+def shared_runtime(device: int = 0) -> Runtime:
+    """The process-wide runtime of a device.  The embedding client and the vector store use it by default, so that the
+    encoder's output buffer and the index live on one device and one stream and a batch can go from one to the other
+    without touching host memory (Encoder.embed_ids_into).  Never closed explicitly: it lives as long as the process."""
+    with _shared_lock:
+        rt = _shared_runtimes.get(int(device))
+        if rt is None or not rt._h:
+            rt = Runtime(device=int(device))
+            _shared_runtimes[int(device)] = rt
+        return rt
+
+
 class Index:
     """HBM-resident vector index (sc_index): FLAT or IVF_FLAT, metric IP / L2 / COSINE."""
 
@@ -234,6 +262,19 @@ class Index:
         if r.shape != (v.shape[0],):
             raise ValueError("rows must have one entry per vector")
         _check(lib().sc_index_overwrite(self.handle, v.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), v.shape[0]))
+
+    def put_rows(self, vecs, rows) -> None:
+        """rows[i] <- vecs[i]; a row number is an existing row (replace) or the next free one (append)."""
+        v = _as_f32(vecs, self.dim)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        if r.shape != (v.shape[0],):
+            raise ValueError("rows must have one entry per vector")
+        _check(lib().sc_index_put_rows(self.handle, v.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), v.shape[0]))
+
+    def put_rows_dev(self, vecs_ptr: int, rows) -> None:
+        """Same with a DEVICE pointer to tight [n, dim] f32 vectors (e.g. a torch tensor's data_ptr())."""
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        _check(lib().sc_index_put_rows_dev(self.handle, C.c_void_p(int(vecs_ptr)), r.ctypes.data_as(C.c_void_p), r.shape[0]))
 
     def get_rows(self, first: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dim), dtype=np.float32)
@@ -342,6 +383,20 @@ class Encoder:
         out = np.empty((B, self.hidden), dtype=np.float32)
         _check(lib().sc_encoder_embed_ids(self.handle, ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S,
                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def embed_ids_into(self, ids: np.ndarray, lens: np.ndarray, index: "Index", rows: np.ndarray, want_host: bool = False) -> "np.ndarray | None":
+        """Embed one batch and store the vectors in `index` rows `rows` (existing rows are replaced, the next free rows
+        appended) without a trip through host memory; returns the vectors only if want_host."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        if ids.ndim != 2 or lens.shape != (ids.shape[0],) or rows.shape != (ids.shape[0],):
+            raise ValueError("ids must be [B, S], lens [B] and rows [B]")
+        B, S = ids.shape
+        out = np.empty((B, self.hidden), dtype=np.float32) if want_host else None
+        _check(lib().sc_encoder_embed_ids_into(self.handle, ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S, index.handle,
+                                               rows.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p) if want_host else None))
         return out
 
     def embed_ids_dev(self, ids_ptr: int, lens_ptr: int, B: int, S: int, out_ptr: int) -> None:

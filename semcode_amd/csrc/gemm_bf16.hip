@@ -207,11 +207,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_BIAS_RES && !DBG)
-        gemm_tile256_mainloop<0>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
-                                 ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem});
+    // DBG bits: 1 no in-loop DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads (ablations, outputs meaningless);
+    //           32 s_setprio 1 for waves 4..7 (real results)
+    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0) | ((DBG & 32) ? 8 : 0);
+    if (EPI == EPI_BIAS_RES && !(DBG & 31))
+        gemm_tile256_mainloop<ML>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
+                                  ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem});
     else
-        gemm_tile256_mainloop<(DBG & 3) | ((DBG & 16) ? 4 : 0)>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
+        gemm_tile256_mainloop<ML>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
     gemm256_stamp(a, blockIdx.x, 3);
     if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
         float sink = 0.f;
@@ -242,6 +245,23 @@ void sc_gemm_set_debug(int v) { g_gemm_dbg = v; }
 static bool g_force_tile128 = false;
 void sc_gemm_force_tile128(bool on) { g_force_tile128 = on; }
 
+template <int EPI, int DBG>
+static void launch256(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    static bool attr = false;  // one per instantiation
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, DBG>), grid, block, T_LDS_BYTES, s, a);  // 128 KiB pipeline + 18 KiB epilogue staging
+}
+template <int DBG>
+static void launch256_epi(int epi, const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    if (epi == EPI_BIAS_GELU) launch256<EPI_BIAS_GELU, DBG>(a, grid, block, s);
+    else if (epi == EPI_BIAS_RES) launch256<EPI_BIAS_RES, DBG>(a, grid, block, s);
+    else launch256<EPI_BIAS, DBG>(a, grid, block, s);
+}
+static int g_gemm_mode = 0;  // main-loop variant of the product path (see gemm256_bf16_kernel)
+
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
                          int ldc, int M, int N, int K, hipStream_t s) {
     GemmArgs a;
@@ -254,37 +274,19 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
         a.tiles_n = N / T_BN;
         a.ntiles = (M / T_BM) * a.tiles_n;
-        const size_t lds256 = T_LDS_BYTES;  // 128 KiB pipeline + 18 KiB epilogue staging
-        static bool attr256 = false;
-        if (!attr256) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            attr256 = true;
-        }
         dim3 grid((unsigned)a.ntiles), block(512);
-        if (g_gemm_dbg) {  // diagnostic variants (sc_diag_gemm_bench); results are meaningless
-            static bool attrd = false;
-            if (!attrd) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI_BIAS, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-
-                attrd = true;
-            }
-            if (g_gemm_dbg == 1) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 1>), grid, block, lds256, s, a);
-            else if (g_gemm_dbg == 2) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 2>), grid, block, lds256, s, a);
-            else if (g_gemm_dbg == 4) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 4>), grid, block, lds256, s, a);
-            else if (g_gemm_dbg == 21) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 21>), grid, block, lds256, s, a);
-
-            else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_BIAS, 5>), grid, block, lds256, s, a);
-            return;
+        static const char* env_mode = getenv("SC_GEMM_MODE");  // A/B experiment: 32 = s_setprio 1 for waves 4..7
+        const int mode = g_gemm_dbg ? g_gemm_dbg : (env_mode ? atoi(env_mode) : g_gemm_mode);
+        switch (mode) {  // ablations (sc_diag_gemm_bench): results are meaningless
+            case 1: launch256<EPI_BIAS, 1>(a, grid, block, s); return;
+            case 2: launch256<EPI_BIAS, 2>(a, grid, block, s); return;
+            case 4: launch256<EPI_BIAS, 4>(a, grid, block, s); return;
+            case 5: launch256<EPI_BIAS, 5>(a, grid, block, s); return;
+            case 21: launch256<EPI_BIAS, 21>(a, grid, block, s); return;
+            default: break;
         }
-        if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_GELU>, grid, block, lds256, s, a);
-        else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS_RES>, grid, block, lds256, s, a);
-        else hipLaunchKernelGGL(gemm256_bf16_kernel<EPI_BIAS>, grid, block, lds256, s, a);
+        if (mode == 32) launch256_epi<32>(epi, a, grid, block, s);
+        else launch256_epi<0>(epi, a, grid, block, s);
         return;
     }
     a.tiles_n = N / G_BN;

@@ -338,6 +338,73 @@ extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const i
     return SC_OK;
 }
 
+// rows[i] <- vecs[i], appends allowed (see include/semcode_hip.h sc_index_put_rows).  vecs: host or device [n, dim].
+sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on_device, const int64_t* rows, int64_t n, const char* who) {
+    int64_t next = ix->n, min_old = INT64_MAX;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = rows[i];
+        if (r == next) ++next;
+        else if (r >= 0 && r < ix->n) min_old = std::min(min_old, r);
+        else return sc_fail(SC_ERR_INVALID, "%s: rows[%lld] = %lld is neither an existing row [0,%lld) nor the next free row %lld", who, (long long)i,
+                            (long long)r, (long long)ix->n, (long long)next);
+    }
+    if (next > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "%s: more than 2^32 rows per shard", who);
+    {
+        std::vector<int64_t> sorted(rows, rows + n);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return sc_fail(SC_ERR_INVALID, "%s: row numbers must be distinct", who);
+    }
+    sc_status st = sc_ivf_untrain_locked(ix);
+    if (st) return st;
+    st = ensure_rows(ix, next, false);
+    if (st) return st;
+    hipStream_t s = ix->rt->stream;
+    if (vecs_on_device) {
+        st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)n * 8);
+        if (st) return st;
+        SC_HIP(hipMemcpyAsync(ix->stage, rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        sc_launch_ingest_rows(vecs, (const int64_t*)ix->stage, 0, n, ix->dim, ix->X, ix->ld, ix->xnorm, s);
+        SC_HIP(hipGetLastError());
+    } else {
+        const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4 + 8));
+        for (int64_t off = 0; off < n; off += chunk) {
+            const int64_t m = std::min(chunk, n - off);
+            const size_t vbytes = ((size_t)m * ix->dim * 4 + 15) & ~(size_t)15;
+            st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, vbytes + (size_t)m * 8);
+            if (st) return st;
+            int64_t* drows = (int64_t*)((char*)ix->stage + vbytes);
+            SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
+            SC_HIP(hipMemcpyAsync(drows, rows + off, (size_t)m * 8, hipMemcpyHostToDevice, s));
+            sc_launch_ingest_rows((const float*)ix->stage, drows, 0, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
+            SC_HIP(hipGetLastError());
+            SC_HIP(hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+        }
+    }
+    ix->n = next;
+    ix->trained = false;
+    if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the bf16 shadow; appended rows get theirs lazily
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_put_rows(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n) {
+    if (!ix || n < 0 || (n > 0 && (!vecs || !rows))) return sc_fail(SC_ERR_INVALID, "sc_index_put_rows: bad argument");
+    if (n == 0) return SC_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    return sc_index_put_rows_locked(ix, vecs, false, rows, n, "sc_index_put_rows");
+}
+
+extern "C" sc_status sc_index_put_rows_dev(sc_index* ix, const float* vecs_dev, const int64_t* rows, int64_t n) {
+    if (!ix || n < 0 || (n > 0 && (!vecs_dev || !rows))) return sc_fail(SC_ERR_INVALID, "sc_index_put_rows_dev: bad argument");
+    if (n == 0) return SC_OK;
+    std::lock_guard<std::mutex> g(ix->mu);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    sc_status st = sc_index_put_rows_locked(ix, vecs_dev, true, rows, n, "sc_index_put_rows_dev");
+    if (st) return st;
+    SC_HIP(hipStreamSynchronize(ix->rt->stream));  // `rows` is the caller's (pageable) memory: do not return while its copy may be pending
+    return SC_OK;
+}
+
 extern "C" sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, float* out) {
     if (!ix || n < 0 || first < 0 || (n > 0 && !out)) return sc_fail(SC_ERR_INVALID, "sc_index_get_rows: bad argument");
     std::lock_guard<std::mutex> g(ix->mu);

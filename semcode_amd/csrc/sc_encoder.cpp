@@ -338,6 +338,35 @@ extern "C" sc_status sc_encoder_embed_ids(sc_encoder* e, const int32_t* ids, con
     return SC_OK;
 }
 
+extern "C" sc_status sc_encoder_embed_ids_into(sc_encoder* e, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, sc_index* ix,
+                                               const int64_t* rows, float* out) {
+    if (!ix || !rows) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into: NULL index / rows");
+    sc_status st = check_embed_args(e, ids, lens, B, S, rows);
+    if (st) return st;
+    if (ix->rt != e->rt) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into: encoder and index belong to different runtimes");
+    if (ix->dim != e->cfg.hidden) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into: index dim %d != encoder hidden %d", ix->dim, e->cfg.hidden);
+    std::lock_guard<std::mutex> g(e->mu);
+    SC_HIP(hipSetDevice(e->rt->device));
+    st = ensure_ws(e, B, S);
+    if (st) return st;
+    hipStream_t s = e->rt->stream;
+    SC_HIP(hipMemcpyAsync(e->ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(e->lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    st = forward_locked(e, e->ids, e->lens, B, S, e->pooled);
+    if (st) return st;
+    {
+        std::lock_guard<std::mutex> gi(ix->mu);  // lock order: encoder, then index (nothing takes them the other way round)
+        st = sc_index_put_rows_locked(ix, e->pooled, true, rows, B, "sc_encoder_embed_ids_into");
+    }
+    if (st) {
+        hipStreamSynchronize(s);
+        return st;
+    }
+    if (out) SC_HIP(hipMemcpyAsync(out, e->pooled, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
 extern "C" sc_status sc_encoder_info(sc_encoder* e, sc_encoder_cfg* cfg_out) {
     if (!e || !cfg_out) return sc_fail(SC_ERR_INVALID, "sc_encoder_info: NULL argument");
     *cfg_out = e->cfg;

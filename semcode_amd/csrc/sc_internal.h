@@ -80,4 +80,6 @@ sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int3
 sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
+// upsert body shared by sc_index_put_rows{,_dev} and sc_encoder_embed_ids_into; caller holds ix->mu and has set the device
+sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on_device, const int64_t* rows, int64_t n, const char* who);
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe);

@@ -79,8 +79,8 @@ class MI355XEmbeddings:
         self._cfg.update(cfg or {})
         self.max_tokens = min(self.max_tokens, self._cfg["max_pos"])
         self._fast_tokenizer: Any = None
-        self._owns_runtime = runtime is None
-        self._runtime = runtime or _native.Runtime(device=int(device if device is not None else getattr(settings, "mi355x_device", 0)))
+        self._owns_runtime = False  # an explicit runtime is the caller's; the default one is shared with the vector store
+        self._runtime = runtime or _native.shared_runtime(int(device if device is not None else getattr(settings, "mi355x_device", 0)))
         weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
         if isinstance(weights, (str, Path)):
             weights = load_weight_blob(weights, self._cfg["layers"])
@@ -133,6 +133,16 @@ class MI355XEmbeddings:
     def embed_ids_array(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512), lens [B] -> [B, hidden] f32."""
         return self._encoder.embed_ids(ids, lens)
+
+    def embed_ids_into(self, store: Any, ids: np.ndarray, lens: np.ndarray, rows: np.ndarray, want_host: bool = False) -> "np.ndarray | None":
+        """Embed pre-tokenised input and write the vectors into `store`'s device index at `rows` (store.plan_rows),
+        device to device.  The store must sit on this client's runtime (the default for both)."""
+        index = getattr(store, "_collection", None)
+        if index is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        if getattr(store, "_runtime", None) is not self._runtime:
+            raise RuntimeError("embed_ids_into: the vector store and the embedding client use different runtimes")
+        return self._encoder.embed_ids_into(ids, lens, index, rows, want_host=want_host)
 
     def close(self) -> None:
         self._encoder.close()

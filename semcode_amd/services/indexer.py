@@ -14,6 +14,8 @@ workspace copy), .language, .start_line, .end_line, .symbol.
 from __future__ import annotations
 
 import hashlib
+import queue
+import threading
 from pathlib import Path
 from typing import Any, Callable, List, Optional, Sequence
 
@@ -70,3 +72,69 @@ def build_payloads(repo_name: str, repo_path: Path, chunks: Sequence[Any], embed
             )
         )
     return payloads
+
+
+def ingest_chunks(repo_name: str, repo_path: Path, chunks: Sequence[Any], embedding_client: Any, vector_store: Any,
+                  embed_progress: Optional[Callable[[int, int], None]] = None,
+                  upsert_progress: Optional[Callable[[int, int], None]] = None, batch_size: Optional[int] = None) -> int:
+    """`_build_payloads` + `upsert_embeddings` (indexer.py:94-114) as one pipelined pass for the MI355X backend.
+
+    What differs from the reference's two loops, and only in speed: (1) no `list[float]` is ever built -- a batch goes
+    from the encoder's device buffer into the index rows (MilvusVectorStore.upsert_encoded); (2) a producer thread
+    tokenises batch i+1 (C++ tokenizer, GIL released) while the device embeds batch i; (3) the batch is
+    settings.mi355x_ingest_batch chunks (default 256) rather than embedding_batch_size = 64, since 64 x 256 tokens do not
+    fill the chip.  What does not differ: chunk ids (make_chunk_id), payload mapping, replace-by-primary-key, and both
+    progress protocols -- (0, total) first, then the cumulative count after every batch; total == 0 reports (0, 0) only
+    and calls nothing.  A primary key that occurs more than once keeps its LAST chunk, as sequential upserts would.
+    Returns the number of chunks embedded and stored.
+    """
+    total = len(chunks)
+    for cb in (embed_progress, upsert_progress):
+        if cb:
+            cb(0, total)
+    if total == 0:
+        return 0
+    ids = [make_chunk_id(repo_name, c.path, c.start_line, c.end_line) for c in chunks]
+    last = {pk: i for i, pk in enumerate(ids)}
+    keep = sorted(last.values())  # later duplicates replace earlier ones; order otherwise preserved
+    bs = int(batch_size or getattr(_resolve_settings(), "mi355x_ingest_batch", 256))
+    bs = max(1, bs)
+    batches = [keep[i:i + bs] for i in range(0, len(keep), bs)]
+    q: "queue.Queue" = queue.Queue(maxsize=2)
+
+    def produce() -> None:
+        try:
+            for idx in batches:
+                q.put((idx, embedding_client.tokenize([chunks[i].content for i in idx])))
+        except BaseException as exc:  # hand the failure to the consumer instead of dying silently
+            q.put(exc)
+        else:
+            q.put(None)
+
+    worker = threading.Thread(target=produce, name="semcode-tokenize", daemon=True)
+    worker.start()
+    done = 0
+    skipped = total - len(keep)
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            idx, (tok, lens) = item
+            metas = [{"repo": repo_name, "path": str(Path(chunks[i].path).relative_to(repo_path)), "language": chunks[i].language,
+                      "start_line": chunks[i].start_line, "end_line": chunks[i].end_line, "symbol": chunks[i].symbol} for i in idx]
+            vector_store.upsert_encoded([ids[i] for i in idx], tok, lens, [chunks[i].content for i in idx], metas, embedding_client)
+            done += len(idx)
+            reported = done + (skipped if done == len(keep) else 0)  # superseded duplicates count as done at the end
+            for cb in (embed_progress, upsert_progress):
+                if cb:
+                    cb(reported, total)
+    finally:
+        while worker.is_alive():  # unblock the producer if we stopped early
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                worker.join(0.05)
+    return len(keep)

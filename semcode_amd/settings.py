@@ -7,7 +7,7 @@ seams usable (and testable) without pydantic_settings, which is absent in the bu
 
 Backend-specific keys ride on the reference's extra="allow" (settings.py:36):
     mi355x_device, mi355x_metric, mi355x_index_type, mi355x_nlist, mi355x_nprobe,
-    mi355x_weights_path, mi355x_vocab_path, mi355x_max_tokens, mi355x_store_path
+    mi355x_weights_path, mi355x_vocab_path, mi355x_max_tokens, mi355x_store_path, mi355x_ingest_batch
 """
 from __future__ import annotations
 
@@ -44,6 +44,7 @@ _DEFAULTS: dict[str, Any] = {
     "mi355x_vocab_path": None,
     "mi355x_max_tokens": 512,
     "mi355x_store_path": None,
+    "mi355x_ingest_batch": 256,       # chunks per embed+upsert batch of services.indexer.ingest_chunks
 }
 
 

@@ -133,7 +133,8 @@ class MilvusVectorStore:
         from .. import _native  # raises loudly if libsemcode_hip.so is missing
 
         if self._runtime is None:
-            self._runtime = _native.Runtime(device=self._device)
+            self._runtime = _native.shared_runtime(self._device)  # shared with the embedding client (device-to-device upserts)
+            self._owns_runtime = False
         log.info("creating_collection %s dim=%d metric=%s index=%s", self.collection_name, self.dim, self.metric, self.index_type)
         return _native.Index(self._runtime, self.dim, metric=self.metric, kind=self.index_type, nlist=self.nlist)
 
@@ -214,6 +215,81 @@ class MilvusVectorStore:
             self._languages[row] = p.metadata.get("language", "")
             self._texts[row] = p.text
             self._metadata[row] = p.metadata
+
+    # ------------------------------------------------------------------ array fast paths
+    def plan_rows(self, ids: Sequence[str]) -> np.ndarray:
+        """Row numbers an upsert of these primary keys writes: the existing row of a known key, else the next free rows in
+        order of appearance.  Keys must be distinct (deduplicate first: the last occurrence wins in an upsert)."""
+        if len(set(ids)) != len(ids):
+            raise ValueError("plan_rows: primary keys must be distinct")
+        rows = np.empty(len(ids), dtype=np.int64)
+        next_row = len(self._ids)
+        for i, pk in enumerate(ids):
+            row = self._row_of.get(pk)
+            if row is None:
+                row = next_row
+                next_row += 1
+            rows[i] = row
+        return rows
+
+    def commit_rows(self, ids: Sequence[str], rows: np.ndarray, texts: Sequence[str], metadatas: Sequence[dict]) -> None:
+        """Scalar columns + primary-key map for rows whose vectors have just been written (same mapping as _upsert_batch)."""
+        for pk, row, text, meta in zip(ids, rows.tolist(), texts, metadatas):
+            cols = (meta.get("repo", ""), meta.get("path", ""), meta.get("language", ""))
+            if row == len(self._ids):
+                self._row_of[pk] = row
+                self._ids.append(pk)
+                self._repos.append(cols[0])
+                self._paths.append(cols[1])
+                self._languages.append(cols[2])
+                self._texts.append(text)
+                self._metadata.append(meta)
+            else:
+                self._repos[row], self._paths[row], self._languages[row] = cols
+                self._texts[row] = text
+                self._metadata[row] = meta
+        self._needs_train = True
+
+    def upsert_arrays(self, ids: Sequence[str], vectors: Any, texts: Sequence[str], metadatas: Sequence[dict],
+                      progress: Optional[Callable[[int, int], None]] = None) -> None:
+        """upsert_embeddings without EmbeddingPayload / list[float] boxing: vectors is one [n, dim] float array.  Same
+        progress protocol and batch size (settings.milvus_upsert_batch_size), same replace-by-primary-key result."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        vec = np.asarray(vectors, dtype=np.float32)
+        total = len(ids)
+        if vec.ndim != 2 or vec.shape != (total, self.dim):
+            raise ValueError(f"embedding dimension mismatch: collection dim={self.dim}, expected [{total}, {self.dim}], got {vec.shape}")
+        if not (len(texts) == len(metadatas) == total):
+            raise ValueError("ids, texts and metadatas must have one entry per vector")
+        if progress:
+            progress(0, total)
+        if total == 0:
+            return
+        batch_size = max(1, getattr(_resolve_settings(), "milvus_upsert_batch_size", 128))
+        done = 0
+        for start in range(0, total, batch_size):
+            stop = min(total, start + batch_size)
+            last = {pk: i for i, pk in enumerate(ids[start:stop], start)}  # repeated key inside a batch: last wins
+            keep = sorted(last.values())
+            b_ids = [ids[i] for i in keep]
+            with self._lock:
+                rows = self.plan_rows(b_ids)
+                self._collection.put_rows(vec[keep], rows)
+                self.commit_rows(b_ids, rows, [texts[i] for i in keep], [metadatas[i] for i in keep])
+            done = stop
+            if progress:
+                progress(done, total)
+
+    def upsert_encoded(self, ids: Sequence[str], token_ids: np.ndarray, lens: np.ndarray, texts: Sequence[str], metadatas: Sequence[dict],
+                       embedding_client: Any) -> None:
+        """One batch, embed + upsert fused: the encoder output goes from its device buffer straight into the index rows."""
+        if self._collection is None:
+            raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
+        with self._lock:
+            rows = self.plan_rows(ids)
+            embedding_client.embed_ids_into(self, token_ids, lens, rows)
+            self.commit_rows(ids, rows, texts, metadatas)
 
     # ------------------------------------------------------------------ search
     def search(self, vector: "list[float]", top_k: int = 10) -> SearchResult:

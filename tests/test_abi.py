@@ -63,3 +63,16 @@ def test_product_never_imports_the_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "libsc_oracle" in t or "sc_oracle.py" in t:
                 offenders.append(str(p.relative_to(ROOT)))
     assert not offenders, offenders
+
+
+def test_shared_runtime_fails_fast_without_a_device():
+    """_native.shared_runtime must not hold the library lock while it creates the runtime (it once did: deadlock on first
+    use).  Without a GPU the call has to come back with the library's own error, not hang."""
+    import torch
+
+    from semcode_amd import _native
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    with pytest.raises(_native.ScError, match="no HIP device"):
+        _native.shared_runtime(0)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from semcode_amd.embeddings.payload import EmbeddingPayload
-from semcode_amd.services import build_payloads, make_chunk_id
+from semcode_amd.services import build_payloads, ingest_chunks, make_chunk_id
 from semcode_amd.settings import settings
 from semcode_amd.storage import MilvusVectorStore
 
@@ -33,6 +33,17 @@ class FakeIndex:
     def overwrite(self, v, rows):
         self.calls.append(("overwrite", [int(r) for r in rows]))
         self.X[np.asarray(rows)] = v
+
+    def put_rows(self, v, rows):
+        rows = [int(r) for r in rows]
+        self.calls.append(("put_rows", rows))
+        v = np.asarray(v, np.float32)
+        for vec, r in zip(v, rows):
+            if r == len(self.X):
+                self.X = np.concatenate([self.X, vec[None]])
+            else:
+                assert 0 <= r < len(self.X), r
+                self.X[r] = vec
 
     def get_rows(self, first, n):
         return self.X[first:first + n].copy()
@@ -195,3 +206,86 @@ def test_save_and_load_round_trip(tmp_path):
     wrong.connect()
     with pytest.raises(ValueError):
         wrong.load(tmp_path / "col")
+
+
+def test_upsert_arrays_equals_upsert_embeddings():
+    """The array fast path ends in the same collection as the payload path: same rows, same columns,
+    replace-by-primary-key, last duplicate wins, same progress protocol (milvus_store.py:98-133)."""
+    rng = np.random.default_rng(0)
+    vec = rng.standard_normal((300, 4)).astype(np.float32)
+    ids = [f"id{i % 290}" for i in range(300)]  # ids 0..9 occur twice (rows 290..299 replace rows 0..9)
+    texts = [f"text {i}" for i in range(300)]
+    metas = [{"repo": "demo", "path": f"src/f{i}.py", "language": "python", "start_line": 1, "end_line": 2, "symbol": None} for i in range(300)]
+    a, b = make_store(), make_store()
+    a.connect(), b.connect()
+    a.upsert_embeddings([EmbeddingPayload(id=ids[i], text=texts[i], vector=vec[i].tolist(), metadata=metas[i]) for i in range(300)])
+    seen = []
+    b.upsert_arrays(ids, vec, texts, metas, progress=lambda x, y: seen.append((x, y)))
+    assert seen == [(0, 300), (128, 300), (256, 300), (300, 300)]
+    assert len(a) == len(b) == 290 and np.array_equal(a._collection.X, b._collection.X)
+    assert a._ids == b._ids and a._texts == b._texts and a._paths == b._paths and a._metadata == b._metadata
+    assert b._texts[3] == "text 293" and b._row_of["id3"] == 3
+    seen = []
+    b.upsert_arrays([], np.zeros((0, 4), np.float32), [], [], progress=lambda x, y: seen.append((x, y)))
+    assert seen == [(0, 0)]
+    with pytest.raises(ValueError):
+        b.upsert_arrays(["x"], np.zeros((1, 5), np.float32), ["t"], [{}])
+    with pytest.raises(ValueError):
+        b.plan_rows(["p", "p"])
+    fresh = make_store()
+    with pytest.raises(RuntimeError, match="Call connect"):
+        fresh.upsert_arrays(["x"], np.zeros((1, 4), np.float32), ["t"], [{}])
+
+
+class TokenizingEmbedding:
+    """Stand-in for MI355XEmbeddings on the fused path: tokenize() + embed_ids_into(); vector = [number of tokens, first id]."""
+
+    def __init__(self, fail_at=None):
+        self.tokenized, self.fail_at = [], fail_at
+
+    def tokenize(self, texts):
+        if self.fail_at is not None and len(self.tokenized) == self.fail_at:
+            raise RuntimeError("tokenizer broke")
+        self.tokenized.append(len(texts))
+        lens = np.array([len(t) for t in texts], np.int32)
+        ids = np.zeros((len(texts), 32), np.int32)
+        ids[:, 0] = [ord(t[0]) for t in texts]
+        return ids, lens
+
+    def embed_ids_into(self, store, ids, lens, rows, want_host=False):
+        vec = np.stack([lens.astype(np.float32), ids[:, 0].astype(np.float32)], axis=1)
+        store._collection.put_rows(vec, rows)
+
+
+def test_ingest_chunks_pipeline(monkeypatch):
+    """services.indexer.ingest_chunks = _build_payloads + upsert_embeddings in one pass (indexer.py:94-114): both progress
+    protocols, the payload mapping, md5 ids and replace-by-primary-key are those of the two reference loops."""
+    monkeypatch.setattr(settings, "mi355x_ingest_batch", 64, raising=False)
+    root = Path("/w/demo")
+    chunks = [Chunk(chr(97 + i % 26) * (i + 1), root / "src" / f"f{i}.py", "python", 10 * i + 1, 10 * i + 9, None) for i in range(130)]
+    store = make_store(dim=2)
+    store.connect()
+    emb, e_seen, u_seen = TokenizingEmbedding(), [], []
+    n = ingest_chunks("demo", root, chunks, emb, store, embed_progress=lambda a, b: e_seen.append((a, b)),
+                      upsert_progress=lambda a, b: u_seen.append((a, b)))
+    assert n == 130 and e_seen == u_seen == [(0, 130), (64, 130), (128, 130), (130, 130)] and emb.tokenized == [64, 64, 2]
+    assert len(store) == 130 and store._ids[3] == make_chunk_id("demo", root / "src" / "f3.py", 31, 39)
+    assert store._metadata[3] == {"repo": "demo", "path": "src/f3.py", "language": "python", "start_line": 31, "end_line": 39, "symbol": None}
+    assert store._texts[3] == "dddd" and store._paths[3] == "src/f3.py" and store._languages[3] == "python"
+    assert np.array_equal(store._collection.X[3], [4.0, float(ord("d"))])
+    # the same repository again, one chunk edited: nothing is appended, the edited row is replaced (idempotent re-ingest)
+    chunks[5] = Chunk("Q" * 7, chunks[5].path, "python", chunks[5].start_line, chunks[5].end_line, None)
+    assert ingest_chunks("demo", root, chunks, TokenizingEmbedding(), store) == 130
+    assert len(store) == 130 and store._texts[5] == "Q" * 7 and np.array_equal(store._collection.X[5], [7.0, float(ord("Q"))])
+    # a primary key that occurs twice keeps its last chunk
+    dup = [chunks[0], Chunk("ZZ", chunks[0].path, "python", chunks[0].start_line, chunks[0].end_line, None)]
+    seen = []
+    assert ingest_chunks("demo", root, dup, TokenizingEmbedding(), store, embed_progress=lambda a, b: seen.append((a, b))) == 1
+    assert seen == [(0, 2), (2, 2)] and store._texts[0] == "ZZ" and len(store) == 130
+    # empty input: (0, 0) only, nothing is called
+    emb, seen = TokenizingEmbedding(), []
+    assert ingest_chunks("demo", root, [], emb, store, embed_progress=lambda a, b: seen.append((a, b))) == 0
+    assert seen == [(0, 0)] and emb.tokenized == []
+    # a failure on the tokenizer thread surfaces in the caller
+    with pytest.raises(RuntimeError, match="tokenizer broke"):
+        ingest_chunks("demo", root, chunks, TokenizingEmbedding(fail_at=1), store)

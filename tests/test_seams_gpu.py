@@ -10,7 +10,9 @@ import pytest
 
 from semcode_amd.embeddings import EmbeddingPayload, EmbeddingProviderFactory
 from semcode_amd.embeddings.providers import MI355XEmbeddings
-from semcode_amd.services import build_payloads
+from semcode_amd import _native
+from semcode_amd.services import build_payloads, ingest_chunks
+from semcode_amd.settings import settings
 from semcode_amd.storage import MilvusVectorStore
 
 pytestmark = pytest.mark.gpu
@@ -111,4 +113,74 @@ def test_provider_with_vocab_uses_native_tokenizer(rt, tmp_path):
     assert [ids[i, : lens[i]].tolist() for i in range(3)] == py and ids.shape[1] == 32
     v = emb.embed_documents_array(texts)
     assert v.shape == (3, 128) and np.isfinite(v).all() and not np.allclose(v[0], v[1])
+    emb.close()
+
+
+def test_put_rows_is_add_plus_overwrite(rt):
+    """sc_index_put_rows{,_dev}: one upsert batch = replace existing rows + append the next free ones, bit for bit what
+    sc_index_add + sc_index_overwrite store (milvus_store.py:119-130)."""
+    rng = np.random.default_rng(5)
+    base, new = rng.standard_normal((40, 96)).astype(np.float32), rng.standard_normal((24, 96)).astype(np.float32)
+    rows = np.array([40, 3, 41, 42, 17, 43] + list(range(44, 60)) + [0, 39], np.int64)  # appends in order, replacements anywhere
+    a = _native.Index(rt, 96, metric="L2", kind="FLAT")
+    a.add(base)
+    a.add(new[rows >= 40])
+    a.overwrite(new[rows < 40], rows[rows < 40])
+    b = _native.Index(rt, 96, metric="L2", kind="FLAT")
+    b.add(base)
+    b.put_rows(new, rows)
+    assert len(b) == len(a) == 60 and np.array_equal(a.get_rows(0, 60), b.get_rows(0, 60))
+    q = rng.standard_normal((8, 96)).astype(np.float32)
+    (da, ra), (db, rb) = a.search(q, k=5), b.search(q, k=5)
+    assert np.array_equal(ra, rb) and np.array_equal(da, db)  # norms were recomputed for replaced rows too
+    import torch
+
+    c = _native.Index(rt, 96, metric="L2", kind="FLAT")
+    c.add(base)
+    dev = torch.from_numpy(new).to("cuda:0")
+    torch.cuda.synchronize()
+    c.put_rows_dev(dev.data_ptr(), rows)
+    assert np.array_equal(c.get_rows(0, 60), a.get_rows(0, 60))
+    for bad in ([61], [5, 5], [-1], [60, 62]):
+        with pytest.raises(_native.ScError):
+            b.put_rows(new[: len(bad)], np.array(bad, np.int64))
+    assert len(b) == 60
+    for ix in (a, b, c):
+        ix.close()
+
+
+def test_ingest_chunks_equals_reference_loops(monkeypatch):
+    """The fused device-to-device ingest stores exactly what _build_payloads + upsert_embeddings store
+    (indexer.py:94-114), vectors bit for bit when both use the same batches."""
+    monkeypatch.setattr(settings, "mi355x_ingest_batch", 64, raising=False)
+    emb = MI355XEmbeddings(cfg=SMALL, synth_seed=3)  # default runtime: shared with the stores below
+    root = Path("/w/demo")
+    texts = [("def f%d(x):\n    return x + %d  # helper number %d " % (i, i, i)) * (1 + i % 5) for i in range(150)]
+    chunks = [Chunk(t, root / "src" / f"m{i}.py", "python", i + 1, i + 3) for i, t in enumerate(texts)]
+    slow = MilvusVectorStore(dim=128, metric="COSINE", index_type="FLAT")
+    slow.connect()
+    slow.upsert_embeddings(build_payloads("demo", root, chunks, emb))
+    fast = MilvusVectorStore(dim=128, metric="COSINE", index_type="FLAT")
+    fast.connect()
+    e_seen, u_seen = [], []
+    assert ingest_chunks("demo", root, chunks, emb, fast, embed_progress=lambda a, b: e_seen.append((a, b)),
+                         upsert_progress=lambda a, b: u_seen.append((a, b))) == 150
+    assert e_seen == u_seen == [(0, 150), (64, 150), (128, 150), (150, 150)]
+    assert len(fast) == len(slow) == 150 and fast._ids == slow._ids and fast._metadata == slow._metadata and fast._texts == slow._texts
+    assert np.array_equal(fast._collection.get_rows(0, 150), slow._collection.get_rows(0, 150))
+    q = emb.embed_documents_array(texts[:20])
+    (df, rf), (ds, rs) = fast.search_batch(q, top_k=5), slow.search_batch(q, top_k=5)
+    assert np.array_equal(rf, rs) and np.array_equal(df, ds) and rf[:, 0].tolist() == list(range(20))
+    # re-ingest with one edited chunk: same rows, one replaced
+    chunks[9] = Chunk("class Edited: pass", chunks[9].path, "python", chunks[9].start_line, chunks[9].end_line)
+    assert ingest_chunks("demo", root, chunks, emb, fast) == 150 and len(fast) == 150
+    got = fast._collection.get_rows(9, 1)[0]
+    assert np.array_equal(got, emb.embed_documents_array(["class Edited: pass"])[0]) and fast._texts[9] == "class Edited: pass"
+    # a store on another runtime is refused loudly rather than copied through the host silently
+    other = MilvusVectorStore(dim=128, metric="COSINE", index_type="FLAT", runtime=_native.Runtime(0))
+    other.connect()
+    with pytest.raises(RuntimeError, match="different runtimes"):
+        ingest_chunks("demo", root, chunks[:4], emb, other)
+    for s_ in (slow, fast, other):
+        s_.close()
     emb.close()
