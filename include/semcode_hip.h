@@ -227,9 +227,12 @@ sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* centroids, int6
 /* Search path selection.  mode 0 (default): exact f32 scan for <= 16 queries, bf16-MFMA coarse scan +
  * exact f32 re-rank + certificate (uncertified queries re-run exactly) for larger batches with
  * k <= 64 -- both return identical results; 1: exact scan only; 2: batched path whenever supported;
- * 3: IVF probe whenever the index is trained (any batch size; used to measure recall). */
+ * 3: per-query IVF probing whenever the index is trained (any batch size; used to measure recall);
+ * 4: list-major IVF probing (the probed lists are streamed once per group of queries that want them; same results as 3).
+ * In mode 0 a trained IVF_FLAT index probes per query while Q * nprobe < nlist, list-major while that is estimated to be
+ * cheaper than the exhaustive paths, and otherwise answers exhaustively (exact results). */
 sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode);
-/* After a search: which path ran (1 exact, 2 batched, 3 ivf probe) and how many queries the batched path had to
+/* After a search: which path ran (1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major) and how many queries the batched path had to
  * re-run through the exact scan because their certificate failed. */
 sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified);
 

@@ -37,6 +37,37 @@ def centroid_mean(S: np.ndarray, assign: np.ndarray, nlist: int, C_old: np.ndarr
     return out
 
 
+def reseed(Cent: np.ndarray, cnt: np.ndarray, ns: int) -> int:
+    """Between Lloyd iterations (sc_ivf.cpp sc_index_train): starved centroids (count < 0.75 average, smallest first, ties by
+    id) are moved onto the largest ones (count > 2 average, largest first, ties by lower id; the size is halved on every
+    split), the two copies pushed apart by the factors (1 +- 2^-10), sign alternating over the dimensions.  In place."""
+    import heapq
+
+    nlist, dim = Cent.shape
+    cnt = [int(c) for c in cnt]
+    donors = sorted(range(nlist), key=lambda c: cnt[c])  # stable: ties keep ascending id
+    heap = [(-cnt[c], c) for c in range(nlist) if cnt[c] * nlist > 2 * ns]
+    heapq.heapify(heap)
+    sg = np.where(np.arange(dim) % 2 == 1, -1.0, 1.0).astype(np.float32) * np.float32(1.0 / 1024.0)
+    up, down = (np.float32(1.0) + sg).astype(np.float32), (np.float32(1.0) - sg).astype(np.float32)
+    moves = 0
+    for e in donors:
+        if not heap or cnt[e] * 4 * nlist >= 3 * ns:
+            break
+        size, b = heapq.heappop(heap)
+        size = -size
+        if size * nlist <= 2 * ns:
+            break
+        v = Cent[b].copy()
+        Cent[e] = v * up
+        Cent[b] = v * down
+        half = size // 2
+        heapq.heappush(heap, (-(size - half), b))
+        heapq.heappush(heap, (-half, e))
+        moves += 1
+    return moves
+
+
 class IvfOracle:
     def __init__(self, X: np.ndarray, metric: str, nlist: int, niter: int = 10):
         X = np.ascontiguousarray(X, dtype=np.float32)
@@ -49,8 +80,11 @@ class IvfOracle:
         crow = (np.arange(nlist, dtype=object) * ns // nlist).astype(np.int64)
         Cent = S[crow].copy()
         am = _assign_metric(metric)
-        for _ in range(niter):
-            Cent = centroid_mean(S, _nearest(Cent, S, am), nlist, Cent)
+        for it in range(niter):
+            assign = _nearest(Cent, S, am)
+            Cent = centroid_mean(S, assign, nlist, Cent)
+            if it + 1 < niter:
+                reseed(Cent, np.bincount(assign, minlength=nlist), ns)
         self.centroids = Cent
         self.assign = _nearest(Cent, X, am)
         self.lists = [np.nonzero(self.assign == c)[0] for c in range(nlist)]

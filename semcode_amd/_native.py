@@ -315,13 +315,13 @@ class Index:
         return {"nlist": n.value, "centroids": cent, "list_sizes": sizes}
 
     def set_search_mode(self, mode: str) -> None:
-        """'auto' | 'exact' | 'batched' | 'ivf' (see sc_index_set_search_mode)."""
-        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3}[mode]))
+        """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (see sc_index_set_search_mode)."""
+        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3, "ivf_listmajor": 4}[mode]))
 
     def last_search_stats(self) -> dict:
         path, unc = C.c_int32(), C.c_int32()
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
-        return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf"}[path.value], "uncertified": unc.value}
+        return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
 
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
         """Device-pointer variant (asynchronous on the runtime's stream)."""

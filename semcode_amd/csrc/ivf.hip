@@ -87,3 +87,26 @@ void sc_launch_rows_to_sample(const float* X, int ld, int dim, const int64_t* ro
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(rows_to_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, ld, dim, rows, n, out_tight);
 }
+
+// ---- re-seeding between Lloyd iterations (sc_ivf.cpp): move m copies centroid b onto the slot of a starved centroid e,
+// the two copies pushed apart by the factor (1 +- 2^-10) with alternating sign over the dimensions.  Moves are applied
+// strictly in order (a large centroid may be split several times), one workgroup, threads over the dimensions.
+__global__ __launch_bounds__(256) void reseed_centroids_kernel(float* __restrict__ C, int dim, const int32_t* __restrict__ moves, int m) {
+    const float eps = 1.0f / 1024.0f;
+    for (int i = 0; i < m; ++i) {
+        const int e = moves[2 * i], b = moves[2 * i + 1];
+        float* ce = C + (size_t)e * dim;
+        float* cb = C + (size_t)b * dim;
+        for (int j = threadIdx.x; j < dim; j += 256) {
+            const float sg = (j & 1) ? -eps : eps;
+            const float v = cb[j];
+            ce[j] = v * (1.0f + sg);
+            cb[j] = v * (1.0f - sg);
+        }
+        __syncthreads();
+    }
+}
+
+void sc_launch_reseed_centroids(float* C_tight, int dim, const int32_t* moves_dev, int m, hipStream_t s) {
+    if (m > 0) hipLaunchKernelGGL(reseed_centroids_kernel, dim3(1), dim3(256), 0, s, C_tight, dim, moves_dev, m);
+}

@@ -657,6 +657,8 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
                                    int64_t* out_rows) {
     ix->last_probed_lists = 0;
     if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
+        return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);
 }
 sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows) {
@@ -664,7 +666,8 @@ sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int3
 }
 
 extern "C" sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode) {
-    if (!ix || mode < 0 || mode > 3) return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact), 2 (batched) or 3 (ivf probe)");
+    if (!ix || mode < 0 || mode > 4)
+        return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact), 2 (batched), 3 (ivf probe per query) or 4 (ivf probe list-major)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->search_mode = mode;
     return SC_OK;

@@ -78,13 +78,19 @@ struct ScanPlan {
 // returns false when (ld, k) cannot be served by the exact kernel
 bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt = 0, int nprobe = 0);
 // X [n, ld], xnorm [n]; Qp [Q, ld] zero padded, qnorm [Q]; partial: plan.partial_bytes
-// perm: stored position -> reported row (NULL = identity); seg_*: IVF probe ranges per query (NULL = all rows)
+// perm: stored position -> reported row (NULL = identity); seg_*: IVF probe ranges per group (NULL = all rows);
+// qmap: query slot -> row of Qp / qnorm (NULL = identity), see scan_exact.hip ScanArgs
 void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp,
                           const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm,
-                          const int* seg_base, const int64_t* seg_rows, int nprobe, hipStream_t s);
+                          const int* seg_base, const int64_t* seg_rows, int nprobe, hipStream_t s, const int32_t* qmap = nullptr);
 // partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k,
                           int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
+// lists_per_query sorted k-lists per query, list j of query q = partial[src[q * lists_per_query + j] * k ...] (src < 0: none);
+// needs 2 * lists_per_query * k * 8 <= 128 KiB (sc_topk_gather_merge_supported)
+bool sc_topk_gather_merge_supported(int lists_per_query, int k);
+void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int32_t* src, int lists_per_query, int Q, int k,
+                                 int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
 
 // scan_batched.hip: bf16 shadow, coarse GEMM + filter phases, selection, exact re-rank
 int sc_batched_kprime(void);
@@ -108,3 +114,4 @@ void sc_launch_centroid_mean(const float* X, int ld, int dim, const int64_t* mem
                              const float* C_old, int ldc_old, hipStream_t s);
 void sc_launch_permute_rows(const float* X, const float* xnorm, const uint32_t* perm, int64_t n, int ld, float* Xo, float* xnorm_o, hipStream_t s);
 void sc_launch_rows_to_sample(const float* X, int ld, int dim, const int64_t* rows, int64_t n, float* out_tight, hipStream_t s);
+void sc_launch_reseed_centroids(float* C_tight, int dim, const int32_t* moves_dev, int m, hipStream_t s);

@@ -68,8 +68,8 @@ struct sc_index {
     int nlist_trained = 0;
     void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
     int last_probed_lists = 0;
-    int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported, 3 IVF probe whenever trained
-    int last_path = 0;                            // 1 exact, 2 batched, 3 ivf probe
+    int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported, 3 / 4 IVF probe per query / list-major whenever trained
+    int last_path = 0;                            // 1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major
     int last_uncertified = 0;
     std::mutex mu;
 };
@@ -79,6 +79,8 @@ sc_status sc_grow(sc_index* ix, void** p, size_t* cap, size_t need);
 sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
+bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, bool flat_is_batched);
+sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
 // upsert body shared by sc_index_put_rows{,_dev} and sc_encoder_embed_ids_into; caller holds ix->mu and has set the device
 sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on_device, const int64_t* rows, int64_t n, const char* who);

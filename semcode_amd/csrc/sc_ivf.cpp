@@ -14,6 +14,10 @@
 //   lists    : every row goes to its nearest centroid; storage is re-ordered list-major (stable by row id)
 //   probe    : per query the nprobe best centroids under the INDEX metric (IP: largest inner product),
 //              then an exact scan of those lists (scan_exact.hip segment mode)
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 
@@ -156,6 +160,51 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
         sc_launch_centroid_mean((const float*)d_sample.p, dim, dim, (const int64_t*)d_members.p, (const int64_t*)d_moff.p, nlist,
                                 (float*)d_cnew.p, qz->X, qz->ld, s);
         SC_HIP(hipGetLastError());
+        // Re-seeding (every iteration but the last, so that final centroids are plain means).  Strided initialisation leaves
+        // some true clusters without a centroid and gives others two; Lloyd iterations cannot repair that, and in high
+        // dimension the orphaned clusters all fall to one "hub" centroid near the global mean (measured on config 5: one list
+        // of 124k rows at a median of 2.4k, list-major probing reading the corpus 26 times over).  So starved centroids
+        // (count < 0.75 average, smallest first) are moved onto the largest ones (count > 2 average, largest first, sizes
+        // halved on every split), as faiss does for empty clusters.  Integer rule + in-order moves: restated exactly by
+        // oracle/ivf_oracle.py.
+        if (it + 1 < niter) {
+            std::vector<int64_t> cnt((size_t)nlist);
+            for (int c = 0; c < nlist; ++c) cnt[(size_t)c] = moff[(size_t)c + 1] - moff[(size_t)c];
+            std::vector<int> donors((size_t)nlist);
+            for (int c = 0; c < nlist; ++c) donors[(size_t)c] = c;
+            std::stable_sort(donors.begin(), donors.end(), [&](int a, int b) { return cnt[(size_t)a] < cnt[(size_t)b]; });
+            auto less_big = [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) {
+                return a.first != b.first ? a.first < b.first : a.second > b.second;  // max-heap: larger size, then lower id
+            };
+            std::vector<std::pair<int64_t, int>> heap;
+            for (int c = 0; c < nlist; ++c)
+                if (cnt[(size_t)c] * nlist > 2 * ns) heap.emplace_back(cnt[(size_t)c], c);
+            std::make_heap(heap.begin(), heap.end(), less_big);
+            std::vector<int32_t> moves;
+            for (int di = 0; di < nlist && !heap.empty(); ++di) {
+                const int e = donors[(size_t)di];
+                if (cnt[(size_t)e] * 4 * nlist >= 3 * ns) break;
+                std::pop_heap(heap.begin(), heap.end(), less_big);
+                const std::pair<int64_t, int> big = heap.back();
+                heap.pop_back();
+                if (big.first * nlist <= 2 * ns) break;
+                moves.push_back(e);
+                moves.push_back(big.second);
+                const int64_t half = big.first / 2;
+                heap.emplace_back(big.first - half, big.second);
+                std::push_heap(heap.begin(), heap.end(), less_big);
+                heap.emplace_back(half, e);
+                std::push_heap(heap.begin(), heap.end(), less_big);
+            }
+            if (!moves.empty()) {
+                Dev d_moves;
+                SC_HIP(hipMalloc(&d_moves.p, moves.size() * 4));
+                SC_HIP(hipMemcpyAsync(d_moves.p, moves.data(), moves.size() * 4, hipMemcpyHostToDevice, s));
+                sc_launch_reseed_centroids((float*)d_cnew.p, dim, (const int32_t*)d_moves.p, (int)(moves.size() / 2), s);
+                SC_HIP(hipGetLastError());
+                SC_HIP(hipStreamSynchronize(s));
+            }
+        }
         SC_HIP(hipStreamSynchronize(s));
         set_centroids((const float*)d_cnew.p);
     }
@@ -212,7 +261,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
 
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe) {
     if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant) return false;
-    if (nprobe < 1 || nprobe > 512 || ix->search_mode == 1 || ix->search_mode == 2) return false;
+    if (nprobe < 1 || nprobe > 512 || ix->search_mode == 1 || ix->search_mode == 2 || ix->search_mode == 4) return false;
     if (nprobe >= ix->nlist_trained) return false;  // probing every list = the exhaustive scan
     if (ix->search_mode == 3) return true;
     // one pass per query over nprobe/nlist of the corpus vs one exhaustive pass per 16 queries (or the
@@ -263,6 +312,182 @@ sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int3
     sc_launch_topk_merge((int)ix->metric, ix->partial, plan.groups, plan.lists, plan.qt, Q, k, ix->row_base, out_dist, out_rows, s);
     SC_HIP(hipGetLastError());
     ix->last_path = 3;
+    ix->last_probed_lists = nprobe;
+    return SC_OK;
+}
+
+// ---- list-major probing for query batches ------------------------------------------------------------------------
+// Per-query probing streams nprobe lists once PER QUERY; with Q * nprobe >= nlist probes every list is wanted by several
+// queries, so the batch is turned round: the (query, list) pairs are bucketed by list, every list is streamed once per
+// group of up to qt queries that probe it (scan_exact_kernel, one row range per group, the group's queries gathered
+// through qmap), and a query's top-k is merged from the nprobe (group, slot) lists it took part in.  Same lists, same exact
+// f32 scores and tie rule as per-query probing, so the results are identical to it.
+static bool ivf_listmajor_plan(const sc_index* ix, int k, int nprobe, ScanPlan* plan) {
+    return sc_scan_exact_plan(ix->ld, 16, k, ix->rt->cus, plan, 0, 1) && sc_topk_gather_merge_supported(nprobe, k);
+}
+
+bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, bool flat_is_batched) {
+    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || Q < 2) return false;
+    if (nprobe < 1 || nprobe > 512 || nprobe >= ix->nlist_trained || (ix->search_mode >= 1 && ix->search_mode <= 3)) return false;
+    ScanPlan plan;
+    if (!ivf_listmajor_plan(ix, k, nprobe, &plan)) return false;
+    if (ix->search_mode == 4) return true;
+    // auto: probe only if streaming the probed lists (once per group of qt queries that want them) costs less than twice
+    // the exhaustive paths' estimate -- those return exact results, but the batched one may have to fall back on clustered
+    // data, hence the factor.  Queries follow the data, so a list is expected to receive pairs in proportion to its length:
+    // work = sum over lists of len * groups(len).  Constants measured on MI355X (profiles/r1q_ivf_*.log): list-major streams
+    // at about 3.5 TB/s (re-reads of popular lists included) after 1.5 ms of coarse probe + planning; the batched exhaustive
+    // path runs at 1.0 PFLOP/s plus about 1 ms, the exact one at 6 TB/s per pass of 16 queries.
+    const double n = (double)ix->n, row_bytes = (double)ix->ld * 4.0, pairs = (double)Q * nprobe;
+    double work_rows = 0.0;
+    for (int l = 0; l < ix->nlist_trained; ++l) {
+        const double len = (double)(ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l]);
+        if (len > 0) work_rows += len * std::max(1.0, std::ceil(pairs * len / (n * plan.qt)));
+    }
+    const double t_lm = work_rows * row_bytes / 3.5e12 + 1.5e-3;
+    double t_flat;
+    if (flat_is_batched) t_flat = std::max(2.0 * n * ix->ld * Q / 1.0e15, n * ix->ld * 2.0 / 5.0e12) + 1.0e-3;
+    else t_flat = std::ceil((double)Q / 16.0) * n * row_bytes / 6.0e12;
+    return t_lm < 2.0 * t_flat;
+}
+
+sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
+                                         int64_t* out_rows) {
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    sc_index* qz = ix->quant;
+    const int nlist = ix->nlist_trained;
+    ScanPlan plan;
+    if (!ivf_listmajor_plan(ix, k, nprobe, &plan)) return sc_fail(SC_ERR_UNSUPPORTED, "ivf list-major search: k=%d / dim=%d / nprobe=%d not supported", k, ix->dim, nprobe);
+    const int qt = plan.qt;
+    const size_t npairs = (size_t)Q * nprobe;
+    // 1. coarse probe under the index metric -> host
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_pd = carve(npairs * 4), o_pr = carve(npairs * 8);
+    sc_status st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, off);
+    if (st) return st;
+    char* b = (char*)ix->ivf_scratch;
+    {
+        std::lock_guard<std::mutex> gq(qz->mu);
+        const sc_metric saved = qz->metric;
+        qz->metric = ix->metric;
+        st = sc_search_flat_locked(qz, q_dev, Q, nprobe, (float*)(b + o_pd), (int64_t*)(b + o_pr));
+        qz->metric = saved;
+        if (st) return st;
+    }
+    static const bool trace = getenv("SC_IVF_TRACE") != nullptr;  // tuning aid: host-side phase times on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::vector<int64_t> probes(npairs);
+    SC_HIP(hipMemcpyAsync(probes.data(), b + o_pr, npairs * 8, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    const double t_probe = since();
+    // 2. bucket the pairs by list (counting sort keeps the queries of a list in ascending order: deterministic groups)
+    std::vector<int> start((size_t)nlist + 1, 0);
+    for (size_t i = 0; i < npairs; ++i) {
+        const int64_t l = probes[i];
+        if (l >= 0 && l < nlist) ++start[(size_t)l + 1];
+    }
+    for (int l = 0; l < nlist; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    std::vector<int32_t> pair_of((size_t)start[(size_t)nlist]);
+    for (size_t i = 0; i < npairs; ++i) {
+        const int64_t l = probes[i];
+        if (l >= 0 && l < nlist) pair_of[(size_t)fill[(size_t)l]++] = (int32_t)i;
+    }
+    // long lists are cut into parts of at most `target` rows (each part its own group) so that no single workgroup streams a
+    // 20k-row list while the others idle; a query then merges up to nprobe * maxparts partial lists
+    int64_t work_rows = 0, longest = 0;
+    for (int l = 0; l < nlist; ++l) {
+        const int m = start[(size_t)l + 1] - start[(size_t)l];
+        const int64_t len = ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
+        if (m == 0 || len <= 0) continue;
+        work_rows += len * ((m + qt - 1) / qt);
+        longest = std::max(longest, len);
+    }
+    int64_t target = std::min<int64_t>(8192, std::max<int64_t>(512, work_rows / ((int64_t)rt->cus * 8)));
+    target = (target + 15) & ~(int64_t)15;
+    int maxparts = (int)((longest + target - 1) / std::max<int64_t>(target, 16));
+    if (maxparts < 1) maxparts = 1;
+    while (maxparts > 1 && !sc_topk_gather_merge_supported(nprobe * maxparts, k)) {  // merge capacity: fewer, longer parts
+        target *= 2;
+        maxparts = (int)((longest + target - 1) / target);
+    }
+    const int L = nprobe * maxparts;
+    std::vector<int32_t> src((size_t)Q * L, -1), qmap;
+    std::vector<int> sb;
+    std::vector<int64_t> sr;
+    int G = 0;
+    for (int l = 0; l < nlist; ++l) {
+        const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
+        const int m = start[(size_t)l + 1] - start[(size_t)l];
+        if (m == 0 || end <= first) continue;  // nobody probes it / empty list
+        const int parts = (int)((end - first + target - 1) / target);
+        for (int c = 0; c < m; c += qt) {
+            for (int part = 0; part < parts; ++part) {
+                const int64_t p0 = first + (int64_t)part * target, p1 = std::min(end, p0 + target);
+                for (int sl = 0; sl < qt; ++sl) {
+                    if (c + sl < m) {
+                        const int32_t pair = pair_of[(size_t)start[(size_t)l] + c + sl];
+                        const int q = pair / nprobe, j = pair - q * nprobe;
+                        qmap.push_back(q);
+                        src[(size_t)q * L + (size_t)j * maxparts + part] = G * qt + sl;
+                    } else {
+                        qmap.push_back(-1);
+                    }
+                }
+                sb.push_back(0);
+                sb.push_back((int)((p1 - p0 + 15) >> 4));
+                sr.push_back(p0);
+                sr.push_back(p1);
+                ++G;
+            }
+        }
+    }
+    const double t_plan = since();
+    // 3. plan tables -> device (they replace the probe results in the scratch buffer), queries padded + normed
+    off = 0;
+    const size_t o_src = carve(src.size() * 4), o_qmap = carve((size_t)G * qt * 4 + 16), o_sb = carve((size_t)G * 2 * 4 + 16),
+                 o_sr = carve((size_t)G * 2 * 8 + 16);
+    st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, off);
+    if (st) return st;
+    b = (char*)ix->ivf_scratch;
+    SC_HIP(hipMemcpyAsync(b + o_src, src.data(), src.size() * 4, hipMemcpyHostToDevice, s));
+    if (G > 0) {
+        SC_HIP(hipMemcpyAsync(b + o_qmap, qmap.data(), (size_t)G * qt * 4, hipMemcpyHostToDevice, s));
+        SC_HIP(hipMemcpyAsync(b + o_sb, sb.data(), (size_t)G * 2 * 4, hipMemcpyHostToDevice, s));
+        SC_HIP(hipMemcpyAsync(b + o_sr, sr.data(), (size_t)G * 2 * 8, hipMemcpyHostToDevice, s));
+    }
+    st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>((size_t)G * qt * k * 8, 16));
+    if (st) return st;
+    sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ix->ld, ix->qnorm, s);
+    // 4. one workgroup per group (grid.y is limited to 65535 groups per launch)
+    hipEvent_t e0, e1;
+    sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+    for (int g0 = 0; g0 < G; g0 += 65535) {
+        const int gn = std::min(65535, G - g0);
+        ScanPlan p = plan;
+        p.groups = gn;
+        p.nwg = 1;
+        p.lists = 1;
+        sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, gn * qt, k, p,
+                             ix->partial + (size_t)g0 * qt * k, ix->perm, (const int*)(b + o_sb) + (size_t)g0 * 2,
+                             (const int64_t*)(b + o_sr) + (size_t)g0 * 2, 1, s, (const int32_t*)(b + o_qmap) + (size_t)g0 * qt);
+    }
+    sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+    // 5. a query's result = merge of the nprobe (group, slot) lists it took part in
+    sc_launch_topk_gather_merge((int)ix->metric, ix->partial, (const int32_t*)(b + o_src), L, Q, k, ix->row_base, out_dist, out_rows, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(s));  // the host plan vectors go out of scope
+    if (trace)
+        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d parts<=%d target=%lld rows | coarse probe + D2H %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms\n",
+                Q, nprobe, qt, G, maxparts, (long long)target, t_probe, t_plan - t_probe, since() - t_plan);
+    ix->last_path = 4;
     ix->last_probed_lists = nprobe;
     return SC_OK;
 }

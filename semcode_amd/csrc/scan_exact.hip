@@ -50,12 +50,16 @@ struct ScanArgs {
     uint64_t* partial;
     // optional: stored position -> reported row id (list-major IVF storage); NULL = identity
     const uint32_t* perm;
-    // optional segment mode (IVF probe, qt == 1, blockIdx.y = query): the query scans nprobe row ranges
-    // seg_rows[q][j] = {first, end}, whose 16-row tiles are numbered consecutively; seg_base[q][j] = first
-    // tile ordinal of range j, seg_base[q][nprobe] = total tiles.
+    // optional segment mode (IVF probe, blockIdx.y = group g): the group's queries scan nprobe row ranges
+    // seg_rows[g][j] = {first, end}, whose 16-row tiles are numbered consecutively; seg_base[g][j] = first
+    // tile ordinal of range j, seg_base[g][nprobe] = total tiles.  Per-query probing: qt == 1, group = query, ranges =
+    // its probed lists.  List-major probing: group = up to qt queries that all probe one list, one range = that list.
     const int* seg_base;
     const int64_t* seg_rows;
     int nprobe;
+    // optional: query slot -> row of Qp / qnorm (list-major probing gathers each group's queries); a group's valid slots
+    // are a prefix, the first negative entry ends it.  NULL = identity.
+    const int32_t* qmap;
 };
 
 struct ScanLds {
@@ -108,7 +112,12 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     const int spt = ld >> 6;  // stages per tile
     const int grp = blockIdx.y;
     const int q0 = grp * a.qt;
-    const int nq = min(a.qt, a.Q - q0);
+    int nq = min(a.qt, a.Q - q0);
+    if (a.qmap) {
+        int c = 0;
+        while (c < nq && a.qmap[q0 + c] >= 0) ++c;
+        nq = c;
+    }
 
     // ---- queries -> LDS (once), thresholds / counters
     {
@@ -116,13 +125,14 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         float* qs = reinterpret_cast<float*>(smem + L.qs);
         for (int c = 0; c < a.qt; ++c) {
             const bool have = c < nq;
-            const float* src = a.Qp + (int64_t)(q0 + (have ? c : 0)) * ld;
+            const int qrow = a.qmap ? (have ? a.qmap[q0 + c] : 0) : q0 + (have ? c : 0);
+            const float* src = a.Qp + (int64_t)qrow * ld;
             for (int kk = tid * 4; kk < ld; kk += 1024) {
                 f32x4 v = have ? *reinterpret_cast<const f32x4*>(src + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(qs + c * qstride + kk) = v;
             }
         }
-        if (tid < 16) reinterpret_cast<float*>(smem + L.qn)[tid] = (tid < nq) ? a.qnorm[q0 + tid] : 1.0f;
+        if (tid < 16) reinterpret_cast<float*>(smem + L.qn)[tid] = (tid < nq) ? a.qnorm[a.qmap ? a.qmap[q0 + tid] : q0 + tid] : 1.0f;
         if (tid < SCAN_WAVES * 16) {
             reinterpret_cast<uint64_t*>(smem + L.thr)[tid] = SC_KEY_MAX;
             reinterpret_cast<unsigned*>(smem + L.cnt)[tid] = 0u;
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         if (a.seg_base) {
             int* sb = reinterpret_cast<int*>(smem + L.seg);
             int64_t* sr = reinterpret_cast<int64_t*>(smem + L.seg + (((unsigned)(a.nprobe + 1) * 4u + 15u) & ~15u));
-            for (int j = tid; j <= a.nprobe; j += 256) sb[j] = a.seg_base[(size_t)q0 * (a.nprobe + 1) + j];
-            for (int j = tid; j < 2 * a.nprobe; j += 256) sr[j] = a.seg_rows[(size_t)q0 * 2 * a.nprobe + j];
+            for (int j = tid; j <= a.nprobe; j += 256) sb[j] = a.seg_base[(size_t)grp * (a.nprobe + 1) + j];
+            for (int j = tid; j < 2 * a.nprobe; j += 256) sr[j] = a.seg_rows[(size_t)grp * 2 * a.nprobe + j];
         }
     }
     __syncthreads();
@@ -312,13 +322,13 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
 
 void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp, const float* qnorm,
                           int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm, const int* seg_base,
-                          const int64_t* seg_rows, int nprobe, hipStream_t s) {
+                          const int64_t* seg_rows, int nprobe, hipStream_t s, const int32_t* qmap) {
     ScanArgs a;
     a.X = X; a.xnorm = xnorm; a.n = n; a.ld = ld; a.Qp = Qp; a.qnorm = qnorm; a.Q = Q; a.qt = p.qt; a.k = k; a.cap = p.cap;
     const int64_t tiles = (n + 15) / 16;
     a.tiles_per_wg = (int)((tiles + p.nwg - 1) / p.nwg);
     a.partial = partial;
-    a.perm = perm; a.seg_base = seg_base; a.seg_rows = seg_rows; a.nprobe = nprobe;
+    a.perm = perm; a.seg_base = seg_base; a.seg_rows = seg_rows; a.nprobe = nprobe; a.qmap = qmap;
     dim3 grid((unsigned)p.nwg, (unsigned)p.groups), block(256);
     static bool attr_done = false;
     if (!attr_done) {

@@ -98,9 +98,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_merge_kernel(int metric, c
 
 // Tree merge in LDS: all `lists` sorted k-lists of one query are loaded once, then halved log2(lists) times; in each
 // round a thread merges two sorted lists with two pointers (k steps).  Used whenever 2 * lists * k keys fit in LDS.
+// lsrc != NULL (list-major IVF probing): list l of query q is the k keys at partial + lsrc[q * lists + l] * k, or empty if negative.
 __global__ __launch_bounds__(MERGE_THREADS) void topk_tree_merge_kernel(int metric, const uint64_t* __restrict__ partial, int lists, int qt, int Q,
                                                                          int k, int64_t row_base, float* __restrict__ out_dist,
-                                                                         int64_t* __restrict__ out_rows) {
+                                                                         int64_t* __restrict__ out_rows, const int32_t* __restrict__ lsrc) {
     extern __shared__ __attribute__((aligned(16))) uint64_t tm_lds[];  // [2][lists * k]
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
@@ -111,7 +112,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_tree_merge_kernel(int metr
     uint64_t* buf1 = tm_lds + (size_t)lists * k;
     for (int i = tid; i < lists * k; i += MERGE_THREADS) {
         const int l = i / k, j = i - l * k;
-        buf0[i] = base[(size_t)l * lstride + j];
+        if (lsrc) {
+            const int v = lsrc[(size_t)q * lists + l];
+            buf0[i] = v >= 0 ? partial[(size_t)v * k + j] : SC_KEY_MAX;
+        } else {
+            buf0[i] = base[(size_t)l * lstride + j];
+        }
     }
     __syncthreads();
     int n = lists;
@@ -153,20 +159,36 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_tree_merge_kernel(int metr
     }
 }
 
+static bool g_tree_attr_done = false;
+
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k, int64_t row_base,
                           float* out_dist, int64_t* out_rows, hipStream_t s) {
     (void)groups;
     const size_t tree_lds = (size_t)2 * lists * k * sizeof(uint64_t);
     if (lists > 0 && tree_lds <= 128 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (!g_tree_attr_done) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_done = true;
+            g_tree_attr_done = true;
         }
         hipLaunchKernelGGL(topk_tree_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), tree_lds, s, metric, partial, lists, qt, Q, k, row_base,
-                           out_dist, out_rows);
+                           out_dist, out_rows, (const int32_t*)nullptr);
         return;
     }
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), 0, s, metric, partial, lists, qt, Q, k, row_base,
                        out_dist, out_rows);
+}
+
+bool sc_topk_gather_merge_supported(int lists_per_query, int k) {
+    return lists_per_query >= 1 && k >= 1 && (size_t)2 * lists_per_query * k * sizeof(uint64_t) <= 128 * 1024;
+}
+
+void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int32_t* src, int lists_per_query, int Q, int k, int64_t row_base,
+                                 float* out_dist, int64_t* out_rows, hipStream_t s) {
+    if (!g_tree_attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        g_tree_attr_done = true;
+    }
+    const size_t tree_lds = (size_t)2 * lists_per_query * k * sizeof(uint64_t);
+    hipLaunchKernelGGL(topk_tree_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), tree_lds, s, metric, partial, lists_per_query, 1, Q, k,
+                       row_base, out_dist, out_rows, src);
 }

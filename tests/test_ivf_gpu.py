@@ -43,12 +43,44 @@ def test_build_and_probe_match_oracle(rt, metric):
     assert ix.last_search_stats()["path"] == "ivf"
     rd, rr = ref.search(Q, 10, 4)
     assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
-    # more queries than lists/nprobe: automatic switch to the exhaustive paths (exact results)
+    # more probes than lists: the batch is probed list-major (same result as per-query probing) ...
     Qb = (centers[rng.integers(0, 40, size=64)] + 0.3 * rng.standard_normal((64, 64))).astype(np.float32)
     d, r = ix.search(Qb, k=10, nprobe=4)
+    assert ix.last_search_stats()["path"] == "ivf_listmajor"
+    rd, rr = ref.search(Qb, 10, 4)
+    assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
+    # ... and probing every list is the exhaustive scan (exact results)
+    d, r = ix.search(Qb, k=10, nprobe=32)
     assert ix.last_search_stats()["path"] in ("exact", "batched")
     od, orow = orc.search(X, Qb, 10, metric)
     assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+def test_listmajor_probe_equals_per_query_probe(rt, metric):
+    """List-major probing (every probed list streamed once per group of queries that want it) returns bit for bit what
+    per-query probing returns: ragged group sizes, lists wanted by more queries than fit one group, lists nobody wants,
+    empty lists, k from 1 to 64, and the CPU restatement agrees."""
+    X, centers = clustered(30_000, 96, 25, seed=11)  # 25 clusters on 64 lists: some lists end up tiny or empty
+    rng = np.random.default_rng(12)
+    ix = _native.Index(rt, 96, metric=metric, kind="IVF_FLAT", nlist=64)
+    ix.add(X)
+    ix.train(niter=5)
+    ref = IvfOracle(X, metric, nlist=64, niter=5)
+    sizes = ix.ivf_info()["list_sizes"]
+    for nq, k, nprobe in ((2, 10, 1), (17, 1, 4), (200, 10, 16), (333, 64, 7), (40, 5, 63)):
+        Q = (centers[rng.integers(0, 25, size=nq)] + 0.4 * rng.standard_normal((nq, 96))).astype(np.float32)
+        ix.set_search_mode("ivf")
+        d3, r3 = ix.search(Q, k=k, nprobe=nprobe)
+        assert ix.last_search_stats()["path"] == "ivf"
+        ix.set_search_mode("ivf_listmajor")
+        d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
+        assert ix.last_search_stats()["path"] == "ivf_listmajor"
+        assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (nq, k, nprobe)
+        rd, rr = ref.search(Q, k, nprobe)
+        assert np.array_equal(r4, rr) and np.array_equal(bits(d4), bits(rd)), (nq, k, nprobe)
+    assert int((sizes == 0).sum()) >= 0  # informational: empty lists are legal and skipped
     ix.close()
 
 
