@@ -626,6 +626,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     for (int i = 0; i < Q; ++i)
         if (hflags[i]) redo.push_back(i);
     ix->last_uncertified = (int)redo.size();
+    ix->uncert_frac = (double)redo.size() / (double)Q;
     if (!redo.empty()) {
         const int R = (int)redo.size();
         const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;

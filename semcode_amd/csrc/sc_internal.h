@@ -71,6 +71,7 @@ struct sc_index {
     int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported, 3 / 4 IVF probe per query / list-major whenever trained
     int last_path = 0;                            // 1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major
     int last_uncertified = 0;
+    double uncert_frac = -1.0;                    // share of queries the last batched exhaustive search had to re-run exactly (-1 = never ran)
     std::mutex mu;
 };
 

@@ -255,6 +255,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
     ix->list_off_h.swap(off);
     ix->nlist_trained = nlist;
     ix->shadow_rows = 0;
+    ix->uncert_frac = -1.0;
     ix->trained = true;
     return SC_OK;
 }
@@ -332,23 +333,29 @@ bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, b
     ScanPlan plan;
     if (!ivf_listmajor_plan(ix, k, nprobe, &plan)) return false;
     if (ix->search_mode == 4) return true;
-    // auto: probe only if streaming the probed lists (once per group of qt queries that want them) costs less than twice
-    // the exhaustive paths' estimate -- those return exact results, but the batched one may have to fall back on clustered
-    // data, hence the factor.  Queries follow the data, so a list is expected to receive pairs in proportion to its length:
-    // work = sum over lists of len * groups(len).  Constants measured on MI355X (profiles/r1q_ivf_*.log): list-major streams
-    // at about 3.5 TB/s (re-reads of popular lists included) after 1.5 ms of coarse probe + planning; the batched exhaustive
-    // path runs at 1.0 PFLOP/s plus about 1 ms, the exact one at 6 TB/s per pass of 16 queries.
+    // auto: probe while that is estimated to be cheaper than the exhaustive paths (which return exact results).
+    // Queries follow the data, so a list is expected to receive (query, list) pairs in proportion to its length:
+    // work = sum over lists of len * groups(len).  The batched exhaustive path re-runs uncertified queries through the exact
+    // scan, which on clustered data (what an IVF index is trained on) can be most of them: its share at the last such search
+    // on this index is fed back (10 % assumed before the first).  Constants measured on MI355X (profiles/r1q_ivf_*.log):
+    // list-major streams 5.5 TB/s after 1.5 ms of coarse probe + planning; batched exhaustive 1.0 PFLOP/s + 1 ms; exact
+    // scan 6 TB/s per pass of qt queries.
     const double n = (double)ix->n, row_bytes = (double)ix->ld * 4.0, pairs = (double)Q * nprobe;
     double work_rows = 0.0;
     for (int l = 0; l < ix->nlist_trained; ++l) {
         const double len = (double)(ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l]);
         if (len > 0) work_rows += len * std::max(1.0, std::ceil(pairs * len / (n * plan.qt)));
     }
-    const double t_lm = work_rows * row_bytes / 3.5e12 + 1.5e-3;
+    const double t_lm = work_rows * row_bytes / 5.5e12 + 1.5e-3;
+    const double t_pass = n * row_bytes / 6.0e12;
     double t_flat;
-    if (flat_is_batched) t_flat = std::max(2.0 * n * ix->ld * Q / 1.0e15, n * ix->ld * 2.0 / 5.0e12) + 1.0e-3;
-    else t_flat = std::ceil((double)Q / 16.0) * n * row_bytes / 6.0e12;
-    return t_lm < 2.0 * t_flat;
+    if (flat_is_batched) {
+        const double redo = (ix->uncert_frac < 0 ? 0.1 : ix->uncert_frac) * Q;
+        t_flat = std::max(2.0 * n * ix->ld * Q / 1.0e15, n * ix->ld * 2.0 / 5.0e12) + 1.0e-3 + std::ceil(redo / plan.qt) * t_pass;
+    } else {
+        t_flat = std::ceil((double)Q / plan.qt) * t_pass;
+    }
+    return t_lm < t_flat;
 }
 
 sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
@@ -484,9 +491,14 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     sc_launch_topk_gather_merge((int)ix->metric, ix->partial, (const int32_t*)(b + o_src), L, Q, k, ix->row_base, out_dist, out_rows, s);
     SC_HIP(hipGetLastError());
     SC_HIP(hipStreamSynchronize(s));  // the host plan vectors go out of scope
-    if (trace)
-        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d parts<=%d target=%lld rows | coarse probe + D2H %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms\n",
-                Q, nprobe, qt, G, maxparts, (long long)target, t_probe, t_plan - t_probe, since() - t_plan);
+    if (trace) {
+        double streamed = 0.0;
+        for (size_t g = 0; g < sr.size(); g += 2) streamed += (double)(sr[g + 1] - sr[g]);
+        streamed *= (double)ix->ld * 4.0;
+        const double t_scan = since() - t_plan;
+        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d parts<=%d target=%lld rows | D2H of probes %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms = %.1f GB at %.2f TB/s\n",
+                Q, nprobe, qt, G, maxparts, (long long)target, t_probe, t_plan - t_probe, t_scan, streamed / 1e9, streamed / 1e9 / t_scan);
+    }
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;
     return SC_OK;

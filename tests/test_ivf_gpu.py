@@ -43,13 +43,20 @@ def test_build_and_probe_match_oracle(rt, metric):
     assert ix.last_search_stats()["path"] == "ivf"
     rd, rr = ref.search(Q, 10, 4)
     assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
-    # more probes than lists: the batch is probed list-major (same result as per-query probing) ...
+    # more probes than lists: the batch is either probed list-major (same result as per-query probing) or, where the
+    # library estimates that to be cheaper, answered exhaustively (exact result)
     Qb = (centers[rng.integers(0, 40, size=64)] + 0.3 * rng.standard_normal((64, 64))).astype(np.float32)
     d, r = ix.search(Qb, k=10, nprobe=4)
-    assert ix.last_search_stats()["path"] == "ivf_listmajor"
+    path = ix.last_search_stats()["path"]
+    assert path in ("exact", "batched", "ivf_listmajor")
+    wd, wr = ref.search(Qb, 10, 4) if path == "ivf_listmajor" else orc.search(X, Qb, 10, metric)
+    assert np.array_equal(r, wr) and np.array_equal(bits(d), bits(wd))
+    ix.set_search_mode("ivf_listmajor")
+    d, r = ix.search(Qb, k=10, nprobe=4)
     rd, rr = ref.search(Qb, 10, 4)
-    assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
-    # ... and probing every list is the exhaustive scan (exact results)
+    assert ix.last_search_stats()["path"] == "ivf_listmajor" and np.array_equal(r, rr) and np.array_equal(bits(d), bits(rd))
+    ix.set_search_mode("auto")
+    # probing every list is the exhaustive scan (exact results)
     d, r = ix.search(Qb, k=10, nprobe=32)
     assert ix.last_search_stats()["path"] in ("exact", "batched")
     od, orow = orc.search(X, Qb, 10, metric)
