@@ -63,7 +63,10 @@ def pmc_traffic():
     gfx950 for 16 B/lane streaming reads).  PMC counters cannot be read from inside this process, so these are
     the committed figures of the same kernels on the same workload; None when the file is absent."""
     try:
-        return json.loads((ROOT / "profiles" / "r1k_pmc_traffic.json").read_text())
+        latest = sorted((ROOT / "profiles").glob("*_pmc_traffic.json"))[-1]  # named per round: the newest one
+        d = json.loads(latest.read_text())
+        d["_file"] = "profiles/" + latest.name
+        return d
     except Exception:
         return None
 
@@ -135,7 +138,7 @@ def bench_embed(ctx, args) -> dict:
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS if gemm_tflops else None,
                      "traffic": (pmc_traffic() or {}).get("gemm256_bf16_kernel", {}).get("traffic_bytes_per_launch") if (B, S) == (256, 256) else None,
-                     "traffic_note": "bytes per launch (avg of the 4 GEMM shapes), profiles/r1k_pmc_traffic.json; algorithmic A+W+C(+R) = 4.56e8",
+                     "traffic_note": f"bytes per launch (avg of the 4 GEMM shapes), {(pmc_traffic() or {}).get('_file')}; algorithmic A+W+C(+R) = 4.56e8",
                      "algorithmic_flops_per_launch": gemm_fl * B / 48, "avg_launch_ms": gemm_ms / max(1, gemm_n), "launches": gemm_n,
                      "attention_avg_launch_ms": attn_ms / max(1, attn_n),
                      "end_to_end_tflops": chunks_s / ctx.world * (gemm_fl + attn_fl) / 1e12,
@@ -237,7 +240,7 @@ def bench_scan(ctx, args) -> dict:
         roof = {"bound": "mfma", "kernel": "scan_coarse_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS if achieved else None,
                 "traffic": coarse_traffic(rows, Q) if dim == 768 else None,
-                "traffic_note": "HBM-side bytes per step over the phase launches (bf16 shadow = rows*ld*2), profiles/r1k_pmc_traffic.json",
+                "traffic_note": f"HBM-side bytes per step over the phase launches (bf16 shadow = rows*ld*2), {(pmc_traffic() or {}).get('_file')}",
                 "algorithmic_flops_per_step": flops / args.steps, "kernel_ms_per_step": scan_ms / args.steps, "launches": scan_n,
                 "select_ms_per_step": merge_ms / args.steps,
                 "hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "achieved_gbs": alg_bytes / step_s / 1e9,
@@ -267,13 +270,14 @@ def bench_scan(ctx, args) -> dict:
 
 
 def coarse_traffic(rows: int, Q: int):
-    """Measured fetch of the coarse kernel = 1.09 x the bf16 shadow at 10M x 768, Q = 1024 (sum of the phase launches)."""
+    """Measured fetch (+ write) of the coarse kernel's phase launches per step at 10M x 768, Q = 1024."""
     t = pmc_traffic()
     if not t or (rows, Q) != (10_000_000, 1024):
         return None
     c = t.get("scan_coarse256_kernel", {})
-    keys = ["grid_35264512", "grid_33554432", "grid_8388608" if False else "grid_2097152", "grid_524288", "grid_131072", "grid_32768", "grid_8192"]
-    # phases of the Q=1024 run: 4.41M, 4.19M, 1.05M (4 q-tiles: grid 8388608 is shared with the Q=256 sweep, use rows*ld*2*1.09), 262k ...
+    if "fetch_bytes_x2_per_step" in c:
+        return c["fetch_bytes_x2_per_step"] + (c.get("write_bytes_per_step") or 0.0)
+    keys = ["grid_35264512", "grid_33554432", "grid_2097152", "grid_524288", "grid_131072", "grid_32768", "grid_8192"]  # r1k layout
     total = sum(c.get(k, {}).get("fetch_bytes_x2_median", 0) for k in keys)
     return total + 1_048_576 * 768 * 2 * 1.09 if total else None
 
