@@ -119,7 +119,9 @@ def bench_embed(ctx, args) -> dict:
 
     for _ in range(args.warmup):
         step()
-    ctx.rt.set_profiling(True)
+    # hipEvent pairs around every 5th GEMM / attention launch: 5 is co-prime with the 4 GEMM shapes of a layer, so all shapes are
+    # sampled equally; pairs around all ~60 launches of a step cost 1.6 % of it (SEMCODE_BENCH_NOPROF=1 measures without any)
+    ctx.rt.set_profiling(0 if os.environ.get("SEMCODE_BENCH_NOPROF") else 5)
     ctx.rt.profile_reset()
     dt = timed(ctx, step, args.steps)
     gemm_ms, gemm_n = ctx.rt.profile_read(2)
@@ -130,7 +132,8 @@ def bench_embed(ctx, args) -> dict:
 
     gemm_fl, attn_fl = encoder_flops_per_chunk(S)
     chunks_s = B * ctx.world * args.steps / dt
-    gemm_tflops = (gemm_fl * B * args.steps) / (gemm_ms * 1e-3) / 1e12 if gemm_n else None
+    # sampled launches cover the 4 shapes equally, so the mean flops of a sampled launch = the mean over all 48 per step
+    gemm_tflops = (gemm_fl * B / 48 * gemm_n) / (gemm_ms * 1e-3) / 1e12 if gemm_n else None
     res = {
         "chunks_per_s": chunks_s,
         "ms_per_step": 1e3 * dt / args.steps,
@@ -139,7 +142,7 @@ def bench_embed(ctx, args) -> dict:
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS if gemm_tflops else None,
                      "traffic": (pmc_traffic() or {}).get("gemm256_bf16_kernel", {}).get("traffic_bytes_per_launch") if (B, S) == (256, 256) else None,
                      "traffic_note": f"bytes per launch (avg of the 4 GEMM shapes), {(pmc_traffic() or {}).get('_file')}; algorithmic A+W+C(+R) = 4.56e8",
-                     "algorithmic_flops_per_launch": gemm_fl * B / 48, "avg_launch_ms": gemm_ms / max(1, gemm_n), "launches": gemm_n,
+                     "algorithmic_flops_per_launch": gemm_fl * B / 48, "avg_launch_ms": gemm_ms / max(1, gemm_n), "launches": 48 * args.steps, "launches_timed": gemm_n,
                      "attention_avg_launch_ms": attn_ms / max(1, attn_n),
                      "end_to_end_tflops": chunks_s / ctx.world * (gemm_fl + attn_fl) / 1e12,
                      "end_to_end_frac": chunks_s / ctx.world * (gemm_fl + attn_fl) / 1e12 / MFMA_BF16_PEAK_TFLOPS},

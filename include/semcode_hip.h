@@ -81,10 +81,11 @@ sc_status sc_runtime_set_stream(sc_runtime* rt, void* stream);
 sc_status sc_runtime_synchronize(sc_runtime* rt);
 /* Device facts for bench.py / DESIGN.md: name (<=255 chars), CU count, total HBM bytes. */
 sc_status sc_runtime_device_info(sc_runtime* rt, char* name, size_t n, int32_t* cus, int64_t* hbm_bytes);
-/* When enabled, the dominant kernel of each search / embed call is bracketed by hipEvents on
- * the runtime's stream (bench.py's roofline figure). */
+/* When enabled (> 0), the dominant kernels of each search / embed call are bracketed by hipEvents on the runtime's
+ * stream (bench.py's roofline figure): every launch of the scan classes; every `enabled`-th launch of the encoder
+ * classes (GEMM, attention), whose ~60 launches per step would otherwise pay 1.6 % for their event pairs. */
 sc_status sc_runtime_set_profiling(sc_runtime* rt, int32_t enabled);
-/* Sum (ms) and count of profiled launches of kernel class `which` since the last reset
+/* Sum (ms) and count of profiled (bracketed) launches of kernel class `which` since the last reset
  * (which: 0 = distance scan, 1 = top-k merge, 2 = encoder GEMM, 3 = attention). Synchronises. */
 sc_status sc_runtime_profile_read(sc_runtime* rt, int32_t which, double* total_ms, int64_t* launches);
 sc_status sc_runtime_profile_reset(sc_runtime* rt);

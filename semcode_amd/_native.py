@@ -176,8 +176,9 @@ class Runtime:
         _check(lib().sc_runtime_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
 
-    def set_profiling(self, enabled: bool) -> None:
-        _check(lib().sc_runtime_set_profiling(self.handle, 1 if enabled else 0))
+    def set_profiling(self, enabled: "bool | int") -> None:
+        """False / 0: off; True / 1: bracket every launch; n > 1: every n-th launch of the encoder kernel classes."""
+        _check(lib().sc_runtime_set_profiling(self.handle, int(enabled)))
 
     def profile_read(self, which: int) -> tuple[float, int]:
         ms, n = C.c_double(), C.c_int64()

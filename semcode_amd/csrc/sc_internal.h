@@ -24,7 +24,8 @@ struct sc_runtime {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool profiling = false;
+    int profiling = 0;                            // 0 off; n >= 1: bracket every n-th launch of the encoder classes (all launches of the scan classes)
+    unsigned prof_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches seen per class since the last reset
     char name[256] = {0};
     int cus = 256;
     int64_t hbm = 0;
