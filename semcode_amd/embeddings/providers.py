@@ -39,8 +39,28 @@ _HF_LAYER = ["attention.self.query.weight", "attention.self.query.bias", "attent
              "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
 
 
-def load_weight_blob(path: "str | Path", layers: int) -> np.ndarray:
-    """Flat f32 blob in ABI order from `.npy` (already flat) or `.safetensors` (HF BERT names, optional "bert." prefix)."""
+# jina-bert-v2 (jina-embeddings-v2-*) checkpoint names: no position table (ALiBi), GLU feed-forward `mlp.gated_layers` [2F, H]
+# without bias (gate = first F rows), `mlp.wo`, `mlp.layernorm`.  Written from the published module layout; no such checkpoint
+# exists offline, so the mapping is only exercised on a file this repo writes with those names (parity unpinned).
+_JINA_HEAD = ["embeddings.word_embeddings.weight", "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+_JINA_LAYER = ["attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+               "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
+               "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias", "mlp.gated_layers.weight", None,  # None: zero bias
+               "mlp.wo.weight", "mlp.wo.bias", "mlp.layernorm.weight", "mlp.layernorm.bias"]
+
+
+def tensors_rows(tensors: dict, name: str) -> int:
+    """Number of rows (output features) of a 2-D checkpoint tensor, with or without the "bert." prefix."""
+    for key in (name, "bert." + name):
+        if key in tensors:
+            return int(np.asarray(tensors[key]).shape[0])
+    raise KeyError(name)
+
+
+def load_weight_blob(path: "str | Path", layers: int, cfg: Optional[dict] = None) -> np.ndarray:
+    """Flat f32 blob in ABI order from `.npy` (already flat) or `.safetensors` (HF BERT names, or jina-bert-v2 names when the
+    file holds `mlp.gated_layers`; optional "bert." prefix).  cfg: the encoder configuration the blob is for (checked
+    against the checkpoint's architecture: a jina file needs alibi + geglu, a BERT file neither)."""
     path = Path(path)
     if path.suffix == ".npy":
         return np.load(path, allow_pickle=False).astype(np.float32).reshape(-1)
@@ -55,9 +75,18 @@ def load_weight_blob(path: "str | Path", layers: int) -> np.ndarray:
                     return np.asarray(tensors[key], dtype=np.float32).reshape(-1)
             raise KeyError(f"{path}: tensor {name!r} not found")
 
-        parts = [get(n) for n in _HF_HEAD]
+        jina = any(k.endswith("encoder.layer.0.mlp.gated_layers.weight") for k in tensors)
+        if cfg is not None and (bool(cfg.get("alibi")) != jina or bool(cfg.get("geglu")) != jina):
+            raise ValueError(f"{path} is a {'jina-bert-v2 (ALiBi + GEGLU)' if jina else 'BERT'} checkpoint but the encoder configuration says "
+                             f"alibi={bool(cfg.get('alibi'))}, geglu={bool(cfg.get('geglu'))}")
+        head, layer = (_JINA_HEAD, _JINA_LAYER) if jina else (_HF_HEAD, _HF_LAYER)
+        parts = [get(n) for n in head]
         for l in range(layers):
-            parts += [get(f"encoder.layer.{l}.{n}") for n in _HF_LAYER]
+            for n in layer:
+                if n is None:  # gated_layers has no bias: 2F zeros
+                    parts.append(np.zeros(tensors_rows(tensors, f"encoder.layer.{l}.mlp.gated_layers.weight"), np.float32))
+                else:
+                    parts.append(get(f"encoder.layer.{l}.{n}"))
         return np.concatenate(parts)
     raise ValueError(f"unsupported weight file {path} (use .npy blob or .safetensors)")
 
@@ -83,7 +112,7 @@ class MI355XEmbeddings:
         self._runtime = runtime or _native.shared_runtime(int(device if device is not None else getattr(settings, "mi355x_device", 0)))
         weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
         if isinstance(weights, (str, Path)):
-            weights = load_weight_blob(weights, self._cfg["layers"])
+            weights = load_weight_blob(weights, self._cfg["layers"], self._cfg)
         if weights is None:
             log.warning("mi355x embeddings: no weights configured (SEMCODE_MI355X_WEIGHTS_PATH); using random-init weights seed=%d", synth_seed)
         self._encoder = _native.Encoder(self._runtime, self._cfg, weights=weights, normalize=normalize, synth_seed=synth_seed)
