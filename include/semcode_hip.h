@@ -139,6 +139,16 @@ sc_status sc_encoder_embed_ids_dev(sc_encoder* enc, const int32_t* ids_dev, cons
 sc_status sc_encoder_embed_ids_into(sc_encoder* enc, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, sc_index* ix,
                                     const int64_t* rows, float* out);
 
+/* The same, pipelined: returns as soon as the batch is enqueued (ids, lens and rows are first copied into pinned staging
+ * owned by the encoder, so the caller's buffers are free immediately).  Up to two batches are in flight; a third call
+ * waits for the first.  The host prepares batch i+1 (tokenising, primary-key bookkeeping) while the device embeds batch i.
+ * Argument errors are reported at once; a failure of the device work is reported by the call that next waits for that
+ * batch (a later _async call or sc_encoder_wait). */
+sc_status sc_encoder_embed_ids_into_async(sc_encoder* enc, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, sc_index* ix,
+                                          const int64_t* rows);
+/* Block until every batch enqueued by sc_encoder_embed_ids_into_async has finished. */
+sc_status sc_encoder_wait(sc_encoder* enc);
+
 /* ----------------------------------------------------------------- tokenizer ---- */
 typedef struct sc_tokenizer sc_tokenizer;
 /* Host-side WordPiece tokenizer (BERT scheme), the step the reference leaves to its provider's library (raw strings

@@ -65,6 +65,8 @@ SIGNATURES = {
     "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_into": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sc_encoder_embed_ids_into_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_encoder_wait": (C.c_int32, [C.c_void_p]),
     "sc_tokenizer_create": (C.c_int32, [C.c_char_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]),
     "sc_tokenizer_destroy": (C.c_int32, [C.c_void_p]),
     "sc_tokenizer_info": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 5),
@@ -386,19 +388,29 @@ class Encoder:
                                           out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def embed_ids_into(self, ids: np.ndarray, lens: np.ndarray, index: "Index", rows: np.ndarray, want_host: bool = False) -> "np.ndarray | None":
+    def embed_ids_into(self, ids: np.ndarray, lens: np.ndarray, index: "Index", rows: np.ndarray, want_host: bool = False,
+                       wait: bool = True) -> "np.ndarray | None":
         """Embed one batch and store the vectors in `index` rows `rows` (existing rows are replaced, the next free rows
-        appended) without a trip through host memory; returns the vectors only if want_host."""
+        appended) without a trip through host memory; returns the vectors only if want_host.  wait=False: return as soon as
+        the batch is enqueued (at most two in flight; call wait() before relying on completion)."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         if ids.ndim != 2 or lens.shape != (ids.shape[0],) or rows.shape != (ids.shape[0],):
             raise ValueError("ids must be [B, S], lens [B] and rows [B]")
         B, S = ids.shape
+        if not wait and not want_host:
+            _check(lib().sc_encoder_embed_ids_into_async(self.handle, ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S,
+                                                         index.handle, rows.ctypes.data_as(C.c_void_p)))
+            return None
         out = np.empty((B, self.hidden), dtype=np.float32) if want_host else None
         _check(lib().sc_encoder_embed_ids_into(self.handle, ids.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), B, S, index.handle,
                                                rows.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p) if want_host else None))
         return out
+
+    def wait(self) -> None:
+        """Block until every batch enqueued with embed_ids_into(..., wait=False) has finished."""
+        _check(lib().sc_encoder_wait(self.handle))
 
     def embed_ids_dev(self, ids_ptr: int, lens_ptr: int, B: int, S: int, out_ptr: int) -> None:
         _check(lib().sc_encoder_embed_ids_dev(self.handle, C.c_void_p(ids_ptr), C.c_void_p(lens_ptr), int(B), int(S), C.c_void_p(out_ptr)))

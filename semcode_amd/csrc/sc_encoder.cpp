@@ -67,6 +67,14 @@ struct sc_encoder {
     int32_t* lens = nullptr;
     float* pooled = nullptr;
     int64_t ws_batch = 0;
+    // pinned host staging for the asynchronous embed -> index path: ids | lens | rows of one batch per slot
+    struct PinSlot {
+        char* host = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } pin[2];
+    int pin_next = 0;
     std::mutex mu;
 };
 
@@ -230,6 +238,10 @@ extern "C" sc_status sc_encoder_destroy(sc_encoder* e) {
     hipStreamSynchronize(e->rt->stream);
     hipFree(e->params);
     hipFree(e->ws);
+    for (auto& slot : e->pin) {
+        if (slot.host) hipHostFree(slot.host);
+        if (slot.done) hipEventDestroy(slot.done);
+    }
     delete e;
     return SC_OK;
 }
@@ -365,6 +377,72 @@ extern "C" sc_status sc_encoder_embed_ids_into(sc_encoder* e, const int32_t* ids
     if (out) SC_HIP(hipMemcpyAsync(out, e->pooled, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
     return SC_OK;
+}
+
+// wait for the batch that last used `slot` (its inputs may be overwritten afterwards); reports a failure of that batch's device work
+static sc_status pin_slot_wait(sc_encoder::PinSlot& slot) {
+    if (!slot.busy) return SC_OK;
+    slot.busy = false;
+    hipError_t he = hipEventSynchronize(slot.done);
+    if (he != hipSuccess) return sc_fail(SC_ERR_HIP, "asynchronous embed batch failed: %s", hipGetErrorString(he));
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_embed_ids_into_async(sc_encoder* e, const int32_t* ids, const int32_t* lens, int32_t B, int32_t S, sc_index* ix,
+                                                     const int64_t* rows) {
+    if (!ix || !rows) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into_async: NULL index / rows");
+    sc_status st = check_embed_args(e, ids, lens, B, S, rows);
+    if (st) return st;
+    if (ix->rt != e->rt) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into_async: encoder and index belong to different runtimes");
+    if (ix->dim != e->cfg.hidden) return sc_fail(SC_ERR_INVALID, "sc_encoder_embed_ids_into_async: index dim %d != encoder hidden %d", ix->dim, e->cfg.hidden);
+    std::lock_guard<std::mutex> g(e->mu);
+    SC_HIP(hipSetDevice(e->rt->device));
+    hipStream_t s = e->rt->stream;
+    sc_encoder::PinSlot& slot = e->pin[e->pin_next];
+    st = pin_slot_wait(slot);  // two batches may be in flight; the third waits for the first
+    if (st) return st;
+    const size_t ids_b = (size_t)B * S * 4, lens_b = align256((size_t)B * 4), rows_b = (size_t)B * 8, need = align256(ids_b) + lens_b + rows_b;
+    if (need > slot.cap) {
+        if (slot.host) hipHostFree(slot.host);
+        slot.host = nullptr;
+        slot.cap = 0;
+        SC_HIP(hipHostMalloc((void**)&slot.host, need, hipHostMallocDefault));
+        slot.cap = need;
+    }
+    if (!slot.done) SC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    char* h_ids = slot.host;
+    char* h_lens = slot.host + align256(ids_b);
+    int64_t* h_rows = (int64_t*)(h_lens + lens_b);
+    memcpy(h_ids, ids, ids_b);
+    memcpy(h_lens, lens, (size_t)B * 4);
+    memcpy(h_rows, rows, rows_b);
+    st = ensure_ws(e, B, S);
+    if (st) return st;
+    SC_HIP(hipMemcpyAsync(e->ids, h_ids, ids_b, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(e->lens, h_lens, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    st = forward_locked(e, e->ids, e->lens, B, S, e->pooled);
+    if (st) return st;
+    {
+        std::lock_guard<std::mutex> gi(ix->mu);
+        st = sc_index_put_rows_locked(ix, e->pooled, true, h_rows, B, "sc_encoder_embed_ids_into_async");
+    }
+    if (st) return st;
+    SC_HIP(hipEventRecord(slot.done, s));
+    slot.busy = true;
+    e->pin_next ^= 1;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_encoder_wait(sc_encoder* e) {
+    if (!e) return sc_fail(SC_ERR_INVALID, "sc_encoder_wait: NULL encoder");
+    std::lock_guard<std::mutex> g(e->mu);
+    SC_HIP(hipSetDevice(e->rt->device));
+    sc_status first = SC_OK;
+    for (auto& slot : e->pin) {
+        sc_status st = pin_slot_wait(slot);
+        if (st && !first) first = st;
+    }
+    return first;
 }
 
 extern "C" sc_status sc_encoder_info(sc_encoder* e, sc_encoder_cfg* cfg_out) {

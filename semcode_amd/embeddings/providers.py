@@ -163,15 +163,21 @@ class MI355XEmbeddings:
         """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512), lens [B] -> [B, hidden] f32."""
         return self._encoder.embed_ids(ids, lens)
 
-    def embed_ids_into(self, store: Any, ids: np.ndarray, lens: np.ndarray, rows: np.ndarray, want_host: bool = False) -> "np.ndarray | None":
+    def embed_ids_into(self, store: Any, ids: np.ndarray, lens: np.ndarray, rows: np.ndarray, want_host: bool = False,
+                       wait: bool = True) -> "np.ndarray | None":
         """Embed pre-tokenised input and write the vectors into `store`'s device index at `rows` (store.plan_rows),
-        device to device.  The store must sit on this client's runtime (the default for both)."""
+        device to device.  The store must sit on this client's runtime (the default for both).  wait=False enqueues the
+        batch and returns (at most two in flight); call wait() before relying on its completion."""
         index = getattr(store, "_collection", None)
         if index is None:
             raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
         if getattr(store, "_runtime", None) is not self._runtime:
             raise RuntimeError("embed_ids_into: the vector store and the embedding client use different runtimes")
-        return self._encoder.embed_ids_into(ids, lens, index, rows, want_host=want_host)
+        return self._encoder.embed_ids_into(ids, lens, index, rows, want_host=want_host, wait=wait)
+
+    def wait(self) -> None:
+        """Block until every batch enqueued with embed_ids_into(..., wait=False) has finished."""
+        self._encoder.wait()
 
     def close(self) -> None:
         self._encoder.close()

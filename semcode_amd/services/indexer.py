@@ -83,7 +83,8 @@ def ingest_chunks(repo_name: str, repo_path: Path, chunks: Sequence[Any], embedd
     from the encoder's device buffer into the index rows (MilvusVectorStore.upsert_encoded); (2) a producer thread
     tokenises batch i+1 (C++ tokenizer, GIL released) while the device embeds batch i; (3) the batch is
     settings.mi355x_ingest_batch chunks (default 256) rather than embedding_batch_size = 64, since 64 x 256 tokens do not
-    fill the chip.  What does not differ: chunk ids (make_chunk_id), payload mapping, replace-by-primary-key, and both
+    fill the chip; (4) batches are enqueued without waiting (two in flight), so the primary-key bookkeeping of batch i+1
+    overlaps the forward of batch i.  What does not differ: chunk ids (make_chunk_id), payload mapping, replace-by-primary-key, and both
     progress protocols -- (0, total) first, then the cumulative count after every batch; total == 0 reports (0, 0) only
     and calls nothing.  A primary key that occurs more than once keeps its LAST chunk, as sequential upserts would.
     Returns the number of chunks embedded and stored.
@@ -125,13 +126,19 @@ def ingest_chunks(repo_name: str, repo_path: Path, chunks: Sequence[Any], embedd
             idx, (tok, lens) = item
             metas = [{"repo": repo_name, "path": str(Path(chunks[i].path).relative_to(repo_path)), "language": chunks[i].language,
                       "start_line": chunks[i].start_line, "end_line": chunks[i].end_line, "symbol": chunks[i].symbol} for i in idx]
-            vector_store.upsert_encoded([ids[i] for i in idx], tok, lens, [chunks[i].content for i in idx], metas, embedding_client)
+            vector_store.upsert_encoded([ids[i] for i in idx], tok, lens, [chunks[i].content for i in idx], metas, embedding_client, wait=False)
             done += len(idx)
+            if done == len(keep):
+                embedding_client.wait()  # the last report means "stored"
             reported = done + (skipped if done == len(keep) else 0)  # superseded duplicates count as done at the end
             for cb in (embed_progress, upsert_progress):
                 if cb:
                     cb(reported, total)
     finally:
+        try:
+            embedding_client.wait()  # never leave enqueued batches behind, whatever happened above
+        except Exception:  # pragma: no cover - the original error is the one to surface
+            pass
         while worker.is_alive():  # unblock the producer if we stopped early
             try:
                 q.get_nowait()

@@ -282,13 +282,15 @@ class MilvusVectorStore:
                 progress(done, total)
 
     def upsert_encoded(self, ids: Sequence[str], token_ids: np.ndarray, lens: np.ndarray, texts: Sequence[str], metadatas: Sequence[dict],
-                       embedding_client: Any) -> None:
-        """One batch, embed + upsert fused: the encoder output goes from its device buffer straight into the index rows."""
+                       embedding_client: Any, wait: bool = True) -> None:
+        """One batch, embed + upsert fused: the encoder output goes from its device buffer straight into the index rows.
+        wait=False: the device work is only enqueued (embedding_client.wait() completes it); searches issued afterwards are
+        ordered behind it on the device stream either way."""
         if self._collection is None:
             raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
         with self._lock:
             rows = self.plan_rows(ids)
-            embedding_client.embed_ids_into(self, token_ids, lens, rows)
+            embedding_client.embed_ids_into(self, token_ids, lens, rows, wait=wait)
             self.commit_rows(ids, rows, texts, metadatas)
 
     # ------------------------------------------------------------------ search

@@ -252,9 +252,13 @@ class TokenizingEmbedding:
         ids[:, 0] = [ord(t[0]) for t in texts]
         return ids, lens
 
-    def embed_ids_into(self, store, ids, lens, rows, want_host=False):
+    def embed_ids_into(self, store, ids, lens, rows, want_host=False, wait=True):
         vec = np.stack([lens.astype(np.float32), ids[:, 0].astype(np.float32)], axis=1)
         store._collection.put_rows(vec, rows)
+        self.pending = not wait
+
+    def wait(self):
+        self.pending = False
 
 
 def test_ingest_chunks_pipeline(monkeypatch):
@@ -269,6 +273,7 @@ def test_ingest_chunks_pipeline(monkeypatch):
     n = ingest_chunks("demo", root, chunks, emb, store, embed_progress=lambda a, b: e_seen.append((a, b)),
                       upsert_progress=lambda a, b: u_seen.append((a, b)))
     assert n == 130 and e_seen == u_seen == [(0, 130), (64, 130), (128, 130), (130, 130)] and emb.tokenized == [64, 64, 2]
+    assert emb.pending is False  # batches are enqueued without waiting, and waited for before the last report
     assert len(store) == 130 and store._ids[3] == make_chunk_id("demo", root / "src" / "f3.py", 31, 39)
     assert store._metadata[3] == {"repo": "demo", "path": "src/f3.py", "language": "python", "start_line": 31, "end_line": 39, "symbol": None}
     assert store._texts[3] == "dddd" and store._paths[3] == "src/f3.py" and store._languages[3] == "python"
