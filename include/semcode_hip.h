@@ -165,7 +165,8 @@ sc_status sc_tokenizer_encode(sc_tokenizer* tok, const char* bytes, const int64_
 
 /* Diagnostics: run ONE encoder kernel on host f32 data (rounded to bf16 on device, result widened
  * back to f32) so that the parity tests can check the GEMM and the attention kernel in isolation.
- * epi: 0 = bias, 1 = bias + erf-GELU, 2 = bias + residual R [M,N].  out [M,N] = A [M,K] * W [N,K]^T.
+ * epi: 0 = bias, 1 = bias + erf-GELU, 2 = bias + residual R [M,N]; + 16: let small shapes take the split-K path the
+ * encoder uses for batches of <= 1024 tokens.  out [M,N] = A [M,K] * W [N,K]^T.
  * M, N multiples of 128, K multiple of 64. */
 sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const float* W, const float* bias, const float* R,
                             int32_t M, int32_t N, int32_t K, float* out);

@@ -18,6 +18,7 @@
 //     4 consecutive output columns of one output row -> 8-byte bf16 stores, bias as one float4;
 //   * workgroup ids are remapped so that the tiles of one 128-row panel run on the same XCD (shared A
 //     panel stays in that XCD's L2).
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm_tile.h"
@@ -34,6 +35,8 @@ struct GemmArgs {
     int tiles_n;       // N / 128
     int ntiles;        // (M/128) * tiles_n
     int order;         // 256-tile kernels: tile walk (see gemm256_tile)
+    int splitk;        // split-K kernels: number of K slices (grid = ntiles * splitk)
+    float* partial;    // split-K kernels: [splitk][M][N] f32 partial products
     unsigned long long* trace;  // diagnostic: per-workgroup time stamps [ntiles][8] (sc_diag_gemm_trace), else nullptr
 };
 
@@ -245,6 +248,67 @@ void sc_gemm_set_debug(int v) { g_gemm_dbg = v; }
 static bool g_force_tile128 = false;
 void sc_gemm_force_tile128(bool on) { g_force_tile128 = on; }
 
+// ---- split-K for small M (a single query or a handful of chunks): with M = 256 a GEMM has 3..12 tiles for 256 CUs and each
+// walks its whole K loop alone (1.7 us per K-tile: 20 us at K = 768, 80 us at K = 3072 -> 1.7 ms per embed_query).  Here
+// tile x K-slice pairs fill the chip, each workgroup writes its raw f32 accumulators, and a second, element-wise kernel
+// sums the slices and applies the epilogue (same formulas as gemm256_epilogue, one bf16 rounding).
+__global__ __launch_bounds__(512) void gemm256_splitk_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (int)blockIdx.x / a.splitk, slice = (int)blockIdx.x - tile * a.splitk;
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = __builtin_amdgcn_readfirstlane(mt * T_BM), n0 = __builtin_amdgcn_readfirstlane(nt * T_BN);
+    const int kslice = a.K / a.splitk, k0 = slice * kslice;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile256_mainloop<0>(a.A + k0, a.lda, m0, a.W + k0, a.ldw, n0, kslice, smem, acc, w, lane);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int wm = w >> 2, wn = w & 3, fr = ln & 15, fq = ln >> 4;
+    float* out = a.partial + ((size_t)slice * a.M + m0 + wm * 128 + fr) * a.N + n0 + wn * 64 + 4 * fq;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(out + (size_t)(mi * 16) * a.N + ni * 16) = acc[ni][mi];
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
+    const int64_t quads = (int64_t)a.M * (a.N / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / (a.N / 4);
+        const int n = (int)(i - m * (a.N / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.bias + n);
+        for (int sidx = 0; sidx < a.splitk; ++sidx) v += *reinterpret_cast<const f32x4*>(a.partial + ((size_t)sidx * a.M + m) * a.N + n);
+        if (EPI == EPI_BIAS_GELU) {
+            const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+            v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+        }
+        if (EPI == EPI_BIAS_RES) {
+            const u16x4 rv = *reinterpret_cast<const u16x4*>(a.R + (size_t)m * a.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(rv[r]);
+        }
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+
+// K slices for a GEMM whose tiles alone would leave most CUs idle: the largest divisor of the K-tile count that keeps at least
+// 3 K-tiles per slice and tiles * slices within the CU count (1 = do not split)
+int sc_gemm_splitk_factor(int M, int N, int K, int cus) {
+    if ((M % T_BM) || (N % T_BN) || M > 1024) return 1;
+    const int tiles = (M / T_BM) * (N / T_BN), nk = K / G_BK;
+    int best = 1;
+    for (int d = 2; d <= nk; ++d)
+        if (nk % d == 0 && nk / d >= 3 && tiles * d <= cus) best = d;
+    return tiles * 2 <= cus ? best : 1;
+}
+
 template <int EPI, int DBG>
 static void launch256(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
     static bool attr = false;  // one per instantiation
@@ -263,7 +327,7 @@ static void launch256_epi(int epi, const GemmArgs& a, dim3 grid, dim3 block, hip
 static int g_gemm_mode = 0;  // main-loop variant of the product path (see gemm256_bf16_kernel)
 
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
-                         int ldc, int M, int N, int K, hipStream_t s) {
+                         int ldc, int M, int N, int K, hipStream_t s, void* splitk_scratch, size_t splitk_scratch_bytes) {
     GemmArgs a;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
@@ -275,6 +339,32 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
         a.tiles_n = N / T_BN;
         a.ntiles = (M / T_BM) * a.tiles_n;
         dim3 grid((unsigned)a.ntiles), block(512);
+        a.splitk = 1;
+        a.partial = nullptr;
+        if (splitk_scratch && !g_gemm_dbg && !g_gemm_trace) {
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+            }
+            const int d = sc_gemm_splitk_factor(M, N, K, cus);
+            if (d > 1 && (size_t)d * M * N * sizeof(float) <= splitk_scratch_bytes) {
+                a.splitk = d;
+                a.partial = (float*)splitk_scratch;
+                static bool attr_sk = false;
+                if (!attr_sk) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_splitk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
+                    attr_sk = true;
+                }
+                hipLaunchKernelGGL(gemm256_splitk_kernel, dim3((unsigned)(a.ntiles * d)), block, T_LDS_BYTES, s, a);
+                const int rb = (int)std::min<int64_t>(((int64_t)M * (N / 4) + 255) / 256, 1024);
+                if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<EPI_BIAS_GELU>, dim3((unsigned)rb), dim3(256), 0, s, a);
+                else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<EPI_BIAS_RES>, dim3((unsigned)rb), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(gemm_splitk_reduce_kernel<EPI_BIAS>, dim3((unsigned)rb), dim3(256), 0, s, a);
+                return;
+            }
+        }
         static const char* env_mode = getenv("SC_GEMM_MODE");  // A/B experiment: 32 = s_setprio 1 for waves 4..7
         const int mode = g_gemm_dbg ? g_gemm_dbg : (env_mode ? atoi(env_mode) : g_gemm_mode);
         switch (mode) {  // ablations (sc_diag_gemm_bench): results are meaningless

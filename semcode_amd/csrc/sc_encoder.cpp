@@ -10,6 +10,7 @@
 // Activations bf16 in HBM ([tokens, H] row-major, tokens padded to 128), weights bf16 [out, in],
 // biases / LayerNorm parameters / embedding tables f32.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -18,8 +19,10 @@
 
 // gemm_bf16.hip / encoder_ops.hip
 bool sc_gemm_bf16_supported(int M, int N, int K);
+// splitk_scratch (optional, f32): lets small-M GEMMs run as tile x K-slice workgroups + a reduce/epilogue kernel (gemm_bf16.hip)
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
-                         int ldc, int M, int N, int K, hipStream_t s);
+                         int ldc, int M, int N, int K, hipStream_t s, void* splitk_scratch = nullptr, size_t splitk_scratch_bytes = 0);
+int sc_gemm_splitk_factor(int M, int N, int K, int cus);
 void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab, int max_pos, const float* wemb, const float* pemb,
                         const float* temb, const float* g, const float* b, float eps, void* out, hipStream_t s);
 void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s);
@@ -67,6 +70,8 @@ struct sc_encoder {
     int32_t* lens = nullptr;
     float* pooled = nullptr;
     int64_t ws_batch = 0;
+    void* splitk = nullptr;  // f32 partial products of the split-K GEMMs (batches of <= 1024 tokens), allocated on first use
+    static constexpr size_t SPLITK_BYTES = 64u << 20;
     // pinned host staging for the asynchronous embed -> index path: ids | lens | rows of one batch per slot
     struct PinSlot {
         char* host = nullptr;
@@ -238,6 +243,7 @@ extern "C" sc_status sc_encoder_destroy(sc_encoder* e) {
     hipStreamSynchronize(e->rt->stream);
     hipFree(e->params);
     hipFree(e->ws);
+    hipFree(e->splitk);
     for (auto& slot : e->pin) {
         if (slot.host) hipHostFree(slot.host);
         if (slot.done) hipEventDestroy(slot.done);
@@ -279,32 +285,38 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
     const int H = c.hidden, F = c.ffn;
     const int tokens = B * S;
     const int M = (tokens + 255) / 256 * 256;
+    void* sk = nullptr;
+    if (M <= 1024) {  // a query or a few chunks: too few tiles for the chip, split K (gemm_bf16.hip)
+        if (!e->splitk) SC_HIP(hipMalloc(&e->splitk, sc_encoder::SPLITK_BYTES));
+        sk = e->splitk;
+    }
+    const size_t skb = sk ? sc_encoder::SPLITK_BYTES : 0;
     sc_launch_embed_ln(ids_dev, tokens, S, H, c.vocab, c.max_pos, e->wemb, e->pemb, e->temb, e->embg, e->embb, c.ln_eps, e->x, s);
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
         hipEvent_t g0, g1;
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS, e->x, H, w.wqkv, H, w.bqkv, nullptr, 0, e->qkv, 3 * H, M, 3 * H, H, s);
+        sc_launch_gemm_bf16(EPI_BIAS, e->x, H, w.wqkv, H, w.bqkv, nullptr, 0, e->qkv, 3 * H, M, 3 * H, H, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         hipEvent_t a0, a1;
         sc_prof_begin(rt, SC_PROF_ATTN, &a0, &a1);
         sc_launch_attention(e->qkv, lens_dev, B, S, H, e->slopes, e->ctx, s);
         sc_prof_end(rt, SC_PROF_ATTN, a0, a1);
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS_RES, e->ctx, H, w.wo, H, w.bo, e->x, H, e->y, H, M, H, H, s);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, e->ctx, H, w.wo, H, w.bo, e->x, H, e->y, H, M, H, H, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         sc_launch_layernorm(e->y, tokens, H, w.ln1g, w.ln1b, c.ln_eps, e->x1, s);
         const void* ffn_in = e->hm;
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        if (c.ffn_type == 1) sc_launch_gemm_bf16(EPI_BIAS, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, 2 * F, M, 2 * F, H, s);
-        else sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s);
+        if (c.ffn_type == 1) sc_launch_gemm_bf16(EPI_BIAS, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, 2 * F, M, 2 * F, H, s, sk, skb);
+        else sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         if (c.ffn_type == 1) {  // GEGLU: gelu(gate) * up
             sc_launch_geglu(e->hm, M, F, e->hg, s);
             ffn_in = e->hg;
         }
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS_RES, ffn_in, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, ffn_in, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         sc_launch_layernorm(e->y, tokens, H, w.ln2g, w.ln2b, c.ln_eps, e->x, s);
     }
@@ -471,11 +483,18 @@ sc_status upload_bf16(const float* host, int64_t n, DevBuf& f32buf, DevBuf& out,
 extern "C" sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float* A, const float* W, const float* bias, const float* R,
                                        int32_t M, int32_t N, int32_t K, float* out) {
     if (!rt || !A || !W || !bias || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bf16: NULL argument");
+    const bool allow_splitk = epi >= 0 && (epi & 16);
+    if (epi >= 0) epi &= 15;
     if (epi < 0 || epi > 2 || (epi == EPI_BIAS_RES && !R)) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_bf16: bad epilogue / missing residual");
     if (!sc_gemm_bf16_supported(M, N, K)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_bf16: need M%%128==0, N%%128==0, K%%64==0");
     SC_HIP(hipSetDevice(rt->device));
     hipStream_t s = rt->stream;
-    DevBuf fa, fw, fr, da, dw, dr, db, dc, fo;
+    DevBuf fa, fw, fr, da, dw, dr, db, dc, fo, sk;
+    size_t sk_bytes = 0;
+    if (allow_splitk) {
+        sk_bytes = (size_t)sc_gemm_splitk_factor(M, N, K, rt->cus) * M * N * 4;
+        if (sk.alloc(sk_bytes) != hipSuccess) return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    }
     sc_status st = upload_bf16(A, (int64_t)M * K, fa, da, s);
     if (st) return st;
     st = upload_bf16(W, (int64_t)N * K, fw, dw, s);
@@ -487,7 +506,7 @@ extern "C" sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float*
     if (db.alloc((size_t)N * 4) != hipSuccess || dc.alloc((size_t)M * N * 2) != hipSuccess || fo.alloc((size_t)M * N * 4) != hipSuccess)
         return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
     SC_HIP(hipMemcpyAsync(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
-    sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
+    sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s, allow_splitk ? sk.p : nullptr, sk_bytes);
     sc_launch_bf16_to_f32(dc.p, (float*)fo.p, (int64_t)M * N, s);
     SC_HIP(hipGetLastError());
     SC_HIP(hipMemcpyAsync(out, fo.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));

@@ -51,17 +51,20 @@ def test_gelu_epilogue_accuracy(rt):
     assert np.all(got[A > 12] == A[A > 12]) and np.all(np.abs(got[A < -12]) < 1e-30)  # saturated tails, no NaN
 
 
+@pytest.mark.parametrize("splitk", [False, True])  # True: the tile x K-slice path small batches (a query) take
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 768, 3072),  # 128x128 tiles
                                    (256, 256, 64), (256, 256, 128), (512, 768, 768), (256, 768, 3072), (1024, 2304, 192)])  # 256x256 tiles
-def test_gemm_kernel(rt, epi, shape):
+def test_gemm_kernel(rt, epi, shape, splitk):
     M, N, K = shape
     rng = np.random.default_rng(M + N + K + epi)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32)
-    got = _native.diag_gemm_bf16(rt, A, W, bias, R if epi == 2 else None, epi=epi)
+    if splitk and shape not in ((512, 768, 768), (256, 768, 3072), (256, 256, 64)):
+        pytest.skip("split-K only differs from the plain path on the shapes it applies to (+ one it must leave alone)")
+    got = _native.diag_gemm_bf16(rt, A, W, bias, R if epi == 2 else None, epi=epi + (16 if splitk else 0))
     ref = bf16_round(A).astype(np.float64) @ bf16_round(W).astype(np.float64).T + bias
     if epi == 1:
         ref = gelu(ref)
