@@ -157,6 +157,32 @@ def test_encoder_batch_and_padding_invariance(rt):
     encn.close()
 
 
+def test_encoder_full_size_properties(rt):
+    """BASELINE configs[1] at full size (256 chunks x 256 tokens, BERT-base shape, the benchmark's device-generated weights),
+    checked through properties that do not need a full-size reference: chunks are independent, so permuting the batch permutes
+    the output bit for bit (256x256-tile GEMMs, attention, LayerNorm, pooling all at their benchmark shapes); a sample of the
+    rows matches the CPU restatement; and the small-batch path (split-K GEMMs) agrees with the large-batch path."""
+    cfg = dict(bo.BERT_BASE)
+    enc = _native.Encoder(rt, cfg, weights=None, synth_seed=0)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(1000, 30000, size=(256, 256)).astype(np.int32)
+    lens = np.full(256, 256, np.int32)
+    lens[[5, 77, 200]] = [1, 100, 255]  # a few ragged chunks among the full ones
+    a = enc.embed_ids(ids, lens)
+    assert np.isfinite(a).all()
+    perm = rng.permutation(256)
+    assert np.array_equal(enc.embed_ids(ids[perm], lens[perm]), a[perm])
+    sample = [0, 5, 77, 200]
+    want = bo.forward(cfg, bo.make_blob(cfg, 0, "bench"), ids[sample], lens[sample])
+    check_pooled(a[[0, 77, 200]], want[[0, 2, 3]])
+    # the 1-token chunk is not averaged over tokens, so it carries the full per-token bf16 noise of 12 layers: looser absolute bar
+    one, ref1 = a[5], want[1]
+    assert one @ ref1 / (np.linalg.norm(one) * np.linalg.norm(ref1)) >= 0.999 and np.abs(one - ref1).max() <= 0.1
+    small = enc.embed_ids(ids[sample[:3]], lens[sample[:3]])  # 768 tokens: split-K GEMMs
+    assert np.abs(small - a[sample[:3]]).max() <= 2e-2  # same arithmetic up to the summation order of the K slices
+    enc.close()
+
+
 def test_encoder_bad_arguments(rt):
     with pytest.raises(_native.ScError):
         _native.Encoder(rt, dict(bo.BERT_BASE, hidden=96, heads=2))  # head dim != 64
