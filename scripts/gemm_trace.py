@@ -32,4 +32,27 @@ for M, N, K, epi, name in shapes:
     first = np.sort(ent)[:256]
     print(f"   first-round entry spread  {first.max() / 100:.2f} us;  last-round drain spread {(np.sort(dr)[-256:].max() - np.sort(dr)[-256:].min()) / 100:.2f} us")
     sys.stdout.flush()
+
+# ---- where does the spread of the main-loop time come from?  by XCD, by dispatch round on a CU, by tile column
+M, N, K, epi, name = 65536, 2304, 768, 0, "qkv"
+T = _native.diag_gemm_trace(rt, M, N, K, epi=epi, launches=3).astype(np.int64)[1]
+hw, xcc = T[:, 0], T[:, 1] & 0xF
+cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+ml = (T[:, 3] - T[:, 2]) / 100.0
+ent = T[:, 2] - T[:, 2].min()
+print(f"{name}: main loop us by XCD:", " ".join(f"{x}:{ml[xcc == x].mean():.2f}" for x in range(8)))
+rounds = np.zeros(len(T), int)
+for c in np.unique(cu):
+    idx = np.where(cu == c)[0]
+    rounds[idx[np.argsort(ent[idx])]] = np.arange(len(idx))
+print("   by dispatch round on its CU:", " ".join(f"{r}:{ml[rounds == r].mean():.2f}" for r in range(rounds.max() + 1)))
+tiles_n = N // 256
+b = np.arange(len(T))  # logical tile of a workgroup: XCD remap + column-major inside groups of 8 row panels (gemm_bf16.hip tile_coords256)
+q, r = len(T) // 8, len(T) % 8
+x = b & 7
+tile = np.where(x < r, x * (q + 1), r * (q + 1) + (x - r) * q) + (b >> 3)
+col = (tile % (8 * tiles_n)) // 8
+print("   by tile column inside its group of 8 row panels:", " ".join(f"{c}:{ml[col == c].mean():.2f}" for c in range(tiles_n)))
+tot = np.array([ml[cu == c].sum() for c in np.unique(cu)])
+print(f"   sum of main loops per CU: mean {tot.mean():.1f} us  min {tot.min():.1f}  max {tot.max():.1f}  (sd of one tile {ml.std():.2f})")
 rt.close()
