@@ -15,6 +15,8 @@
 //                                  column, softmax in registers, P feeds P V straight from the
 //                                  accumulator registers, V fragments by ds_read_b64_tr_b16
 //   mean_pool_kernel  HBM-bound  : 1 workgroup / chunk, masked mean (+ optional L2 normalise) -> f32
+#include <cstdlib>
+
 #include "gemm_tile.h"  // bf16 helpers, LDS-DMA pointer types
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // that only 64 score registers are live (S = 256 runs 2 workgroups per CU, S = 512 no longer spills).
 // FULL = every key of the padded sequence is real (len == S): no per-tile guards or masks.
 // ALIBI: scores get the symmetric linear bias -slope_head * |query - key| (jina-bert-v2 style encoders, no position table).
-template <int KT, bool FULL, bool ALIBI>
+template <int KT, bool FULL, bool ALIBI, int GKMAX = 4>
 static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, char* ostg,
                                                         bf16_t* obase, int H, int len, int nkt, int lane, int qbase, float slope2) {
-    constexpr int GK = KT < 4 ? KT : 4;   // key tiles per group
+    constexpr int GK = KT < GKMAX ? KT : GKMAX;   // key tiles per group
     constexpr int NG = (KT + GK - 1) / GK;
     const int l31 = lane & 31, hh = lane >> 5;
     const float sl2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
@@ -314,44 +316,40 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
             }
         }
     }
-    // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS 16 query
-    // rows at a time (wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
+    // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS 8 query rows
+    // at a time (1 KiB, wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
     xch[l31] = 1.0f / l_run;
     bf16_t* og = reinterpret_cast<bf16_t*>(ostg);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 il = *reinterpret_cast<const f32x4*>(xch + 8 * g4 + 4 * hh);
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            const int g4 = 2 * half + gg;
-            const f32x4 il = *reinterpret_cast<const f32x4*>(xch + 8 * g4 + 4 * hh);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ql = 8 * gg + 4 * hh + c;  // row inside this half
-                og[ql * 64 + l31] = (bf16_t)(pack_bf16x2(o0[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
-                og[ql * 64 + 32 + l31] = (bf16_t)(pack_bf16x2(o1[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
-            }
+        for (int c = 0; c < 4; ++c) {
+            const int ql = 4 * hh + c;  // row inside this block of 8
+            og[ql * 64 + l31] = (bf16_t)(pack_bf16x2(o0[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
+            og[ql * 64 + 32 + l31] = (bf16_t)(pack_bf16x2(o1[4 * g4 + c] * il[c], 0.f) & 0xFFFFu);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ql = 8 * j + (lane >> 3), c = lane & 7;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(ostg + ql * 128 + c * 16);
-            *reinterpret_cast<bf16x8*>(obase + (size_t)(16 * half + ql) * H + c * 8) = v;
-        }
+        const int ql = lane >> 3, c8 = lane & 7;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ostg + ql * 128 + c8 * 16);
+        *reinterpret_cast<bf16x8*>(obase + (size_t)(8 * g4 + ql) * H + c8 * 8) = v;
     }
 }
 
-template <int KT, bool ALIBI>
-__global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
+// NW waves per workgroup (4, or 8 for S = 256: one query block per wave, two key-tile groups of 2 -> half the registers, so that
+// 4 waves instead of 2 share a SIMD and cover each other's MFMA -> softmax -> MFMA dependency stalls)
+template <int KT, bool ALIBI, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
                                                             const float* __restrict__ slopes, bf16_t* __restrict__ ctx) {
     constexpr int S = KT * 32;
-    constexpr int NQB = (KT + 3) / 4;  // query blocks per wave
+    constexpr int NQB = (KT + NW - 1) / NW;  // query blocks per wave
+    constexpr int GKMAX = NW == 8 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     char* Vl = smem + S * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* xch = reinterpret_cast<float*>(smem + 2 * S * 128) + w * 32;  // [4 waves][32] alpha / 1/l exchange
-    char* ostg = smem + 2 * S * 128 + 512 + w * 2048;                    // per-wave [16 q][64 d] bf16 output staging
+    float* xch = reinterpret_cast<float*>(smem + 2 * S * 128) + w * 32;  // [NW waves][32] alpha / 1/l exchange
+    char* ostg = smem + 2 * S * 128 + NW * 128 + w * 1024;               // per-wave [8 q][64 d] bf16 output staging
     const int head = blockIdx.x, b = blockIdx.y;
     const int ld = 3 * H;
     const bf16_t* base = qkv + (size_t)b * S * ld + head * 64;
@@ -361,12 +359,12 @@ __global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const
     const int nkt = (len + 31) >> 5;  // key tiles holding at least one real key; later tiles are skipped entirely
 
     // ---- stage K then V rows [0, 32 nkt) of this (chunk, head): pieces of 8 rows x 128 B = 1 KiB
-    for (int piece = w; piece < nkt * 4; piece += 4) {
+    for (int piece = w; piece < nkt * 4; piece += NW) {
         const int p = piece * 64 + lane;
         const int r = p >> 3, ck = (p & 7) ^ ((r >> 1) & 7);
         __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + H + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
     }
-    for (int piece = w; piece < nkt * 4; piece += 4) {
+    for (int piece = w; piece < nkt * 4; piece += NW) {
         const int p = piece * 64 + lane;
         const int r = p >> 3, cv = (p & 7) ^ (((r >> 1) & 1) << 2);
         __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + 2 * H + cv * 8), (lds_vptr)(Vl + piece * 1024), 16, 0, 0);
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const
     bf16x8 qf[NQB][4];
 #pragma unroll
     for (int i = 0; i < NQB; ++i) {
-        const int qb = w + 4 * i;
+        const int qb = w + NW * i;
         if (qb < KT) {
             const bf16_t* qrow = base + (size_t)(qb * 32 + l31) * ld;
 #pragma unroll
@@ -389,12 +387,12 @@ __global__ __launch_bounds__(256, (KT <= 8 ? 2 : 1)) void attention_kernel(const
 
 #pragma unroll
     for (int i = 0; i < NQB; ++i) {
-        const int qb = w + 4 * i;
+        const int qb = w + NW * i;
         if (qb < KT) {
             bf16_t* obase = ctx + (size_t)(b * S + qb * 32) * H + head * 64;
             const float slope2 = ALIBI ? slopes[head] * 1.44269504088896340736f : 0.f;
-            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true, ALIBI>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
-            else attention_qblock<KT, false, ALIBI>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
+            if (nkt == KT && (len & 31) == 0) attention_qblock<KT, true, ALIBI, GKMAX>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
+            else attention_qblock<KT, false, ALIBI, GKMAX>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
         }
     }
 }
@@ -464,14 +462,20 @@ void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, cons
 }
 template <int KT, bool ALIBI>
 static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, const float* slopes, void* ctx, hipStream_t s) {
-    const size_t lds = (size_t)KT * 32 * 256 + 512 + 4 * 2048;
+    static const char* env = getenv("SC_ATTN_WAVES");  // A/B aid
+    constexpr int NWD = KT == 8 ? 8 : 4;
+    const int nw = (env && KT == 8) ? atoi(env) : NWD;
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + 4 * 1152);
+        if (KT == 8) hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, NWD>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + NWD * 1152);
         done = true;
     }
-    hipLaunchKernelGGL((attention_kernel<KT, ALIBI>), dim3((unsigned)(H / 64), (unsigned)B), dim3(256), lds, s, (const bf16_t*)qkv, lens, H, slopes,
-                       (bf16_t*)ctx);
+    const dim3 grid((unsigned)(H / 64), (unsigned)B);
+    if (KT == 8 && nw == 8)
+        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, NWD>), grid, dim3(NWD * 64), (size_t)KT * 32 * 256 + NWD * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
+    else
+        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, 4>), grid, dim3(256), (size_t)KT * 32 * 256 + 4 * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
 }
 bool sc_attention_supported(int S, int H, int heads) {
     return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512);
