@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(c
                                                             const float* __restrict__ slopes, bf16_t* __restrict__ ctx) {
     constexpr int S = KT * 32;
     constexpr int NQB = (KT + NW - 1) / NW;  // query blocks per wave
-    constexpr int GKMAX = NW == 8 ? 2 : 4;
+    constexpr int GKMAX = (NW == 8 && KT <= 8) ? 2 : 4;  // S = 512 runs one workgroup per CU anyway (LDS): registers are not its limit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     char* Vl = smem + S * 128;
@@ -463,16 +463,16 @@ void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, cons
 template <int KT, bool ALIBI>
 static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, const float* slopes, void* ctx, hipStream_t s) {
     static const char* env = getenv("SC_ATTN_WAVES");  // A/B aid
-    constexpr int NWD = KT == 8 ? 8 : 4;
-    const int nw = (env && KT == 8) ? atoi(env) : NWD;
+    constexpr int NWD = KT >= 8 ? 8 : 4;
+    const int nw = (env && KT >= 8) ? atoi(env) : NWD;
     static bool done = false;
     if (!done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + 4 * 1152);
-        if (KT == 8) hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, NWD>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + NWD * 1152);
+        if (KT >= 8) hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, NWD>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + NWD * 1152);
         done = true;
     }
     const dim3 grid((unsigned)(H / 64), (unsigned)B);
-    if (KT == 8 && nw == 8)
+    if (KT >= 8 && nw == 8)
         hipLaunchKernelGGL((attention_kernel<KT, ALIBI, NWD>), grid, dim3(NWD * 64), (size_t)KT * 32 * 256 + NWD * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
     else
         hipLaunchKernelGGL((attention_kernel<KT, ALIBI, 4>), grid, dim3(256), (size_t)KT * 32 * 256 + 4 * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
