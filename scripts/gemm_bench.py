@@ -8,7 +8,7 @@ variants = [int(v) for v in sys.argv[1:]] or [0, 128]
 for M, N, K, epi, name in shapes:
     row = []
     for v in variants:
-        e = epi if (v in (0, 32, 128) or v >= 1000) else 0  # ablations: 1 no DMA, 2 no MFMA, 4 no epilogue, 5 = 1+4, 21 = MFMA only; 32 = setprio for waves 4..7 (real results)
+        e = epi if (v in (0, 128) or v >= 1000) else 0  # ablations: 1 no DMA, 2 no MFMA, 4 no epilogue, 5 = 1+4, 21 = MFMA only
         ms = _native.diag_gemm_bench(rt, M, N, K, epi=e, iters=10, variant=v)
         row.append(f"v{v}: {ms*1e3:8.1f}us {2.0*M*N*K/ms/1e9:7.1f}TF")
     print(f"{name:6s} M={M} N={N} K={K} epi={epi} | " + " | ".join(row), flush=True)

@@ -211,9 +211,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // DBG bits: 1 no in-loop DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads (ablations, outputs meaningless);
-    //           32 s_setprio 1 for waves 4..7 (real results)
-    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0) | ((DBG & 32) ? 8 : 0);
-    if (EPI == EPI_BIAS_RES && !(DBG & 31))
+    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0);
+    if (EPI == EPI_BIAS_RES && !DBG)
         gemm_tile256_mainloop<ML>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
                                   ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem});
     else
@@ -324,7 +323,6 @@ static void launch256_epi(int epi, const GemmArgs& a, dim3 grid, dim3 block, hip
     else if (epi == EPI_BIAS_RES) launch256<EPI_BIAS_RES, DBG>(a, grid, block, s);
     else launch256<EPI_BIAS, DBG>(a, grid, block, s);
 }
-static int g_gemm_mode = 0;  // main-loop variant of the product path (see gemm256_bf16_kernel)
 
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
                          int ldc, int M, int N, int K, hipStream_t s, void* splitk_scratch, size_t splitk_scratch_bytes) {
@@ -365,9 +363,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
                 return;
             }
         }
-        static const char* env_mode = getenv("SC_GEMM_MODE");  // A/B experiment: 32 = s_setprio 1 for waves 4..7
-        const int mode = g_gemm_dbg ? g_gemm_dbg : (env_mode ? atoi(env_mode) : g_gemm_mode);
-        switch (mode) {  // ablations (sc_diag_gemm_bench): results are meaningless
+        switch (g_gemm_dbg) {  // ablations (sc_diag_gemm_bench): results are meaningless
             case 1: launch256<EPI_BIAS, 1>(a, grid, block, s); return;
             case 2: launch256<EPI_BIAS, 2>(a, grid, block, s); return;
             case 4: launch256<EPI_BIAS, 4>(a, grid, block, s); return;
@@ -375,8 +371,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
             case 21: launch256<EPI_BIAS, 21>(a, grid, block, s); return;
             default: break;
         }
-        if (mode == 32) launch256_epi<32>(epi, a, grid, block, s);
-        else launch256_epi<0>(epi, a, grid, block, s);
+        launch256_epi<0>(epi, a, grid, block, s);
         return;
     }
     a.tiles_n = N / G_BN;

@@ -197,7 +197,7 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 // acc[ni][mi][r] = sum_k A[m0 + wm*128 + mi*16 + (lane&15)][k] * W[n0 + wn*64 + ni*16 + 4*(lane>>4) + r][k]
 // smem: 128 KiB ([2][A tile | W tile]).  All 512 threads of the workgroup must call it.  K % 64 == 0.
 // DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs, bit 2 = skip the fragment reads
-// (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop), bit 3 = s_setprio 1 for waves 4..7.
+// (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).
 // tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
 // reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
 // tile, gemm_bf16.hip) and have it land under those MFMAs.
@@ -224,7 +224,6 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
     Frag256 f0, f1;
     using T = std::true_type;
     using F = std::false_type;
-    if ((DBG & 8) && w >= 4) __builtin_amdgcn_s_setprio(1);
     read_frags256(smem, smem + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
     if (DBG & 4) read_frags256(smem, smem + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
     // One K-tile.  STAGE: a tile kt+2 exists and is requested; NEXT: a tile kt+1 exists and its k-step-0
