@@ -342,7 +342,13 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
 }
 
 // ------------------------------------------------------------------ exact re-rank + certificate
-// One 128-thread workgroup per query: thread j re-scores candidate j with the canonical f32 fmaf chain.
+// One 128-thread workgroup per query: thread j re-scores candidate j with the canonical f32 fmaf chain.  The 128 candidate rows
+// are scattered over the corpus; read row-per-thread, every load instruction touched 64 different cache lines and the kernel
+// took 0.34 ms per 1024 queries.  So the rows are fetched cooperatively, 64 floats of all 128 rows at a time (16 lanes x 16 B
+// = one 256-byte row segment per load), through an LDS tile [128][64 + 4] (the pad keeps the row-per-thread ds_read_b128 of
+// the chain conflict-free), the next tile's loads in flight while this one is multiplied.  The chain itself is unchanged:
+// k = 16 t + 4 g + c, c outer, g inner -- bit-identical scores.
+#define RR_STRIDE 68  // floats per LDS row
 template <int METRIC>
 __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
                                                           const float* __restrict__ Qp, const float* __restrict__ qnorm,
@@ -351,27 +357,52 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
                                                           const int* __restrict__ overflow, int k,
                                                           int64_t row_base, const uint32_t* __restrict__ perm, float* __restrict__ out_dist,
                                                           int64_t* __restrict__ out_rows, int* __restrict__ flags) {
+    static_assert(KPRIME == 128, "the cooperative tile load assumes 128 candidates = 128 threads");
     __shared__ uint64_t keys[KPRIME];
+    __shared__ uint32_t rowid[KPRIME];
+    __shared__ __attribute__((aligned(16))) float tile[KPRIME * RR_STRIDE];
+    __shared__ __attribute__((aligned(16))) float qch[64];
     const int q = blockIdx.x, lane = threadIdx.x;
     const uint64_t ck = best[(size_t)q * KPRIME + lane];
-    uint64_t ek = SC_KEY_MAX;
-    if (ck != SC_KEY_MAX) {
-        const uint32_t row = (uint32_t)ck;
-        const float* x = X + (size_t)row * ld;
-        const float* qv = Qp + (size_t)q * ld;
-        float acc = 0.f;
-        for (int t = 0; t < ld; t += 16) {
+    rowid[lane] = ck != SC_KEY_MAX ? (uint32_t)ck : 0u;  // padding slots re-score row 0 and are discarded below
+    __syncthreads();
+    const int seg = lane & 15, r0 = lane >> 4;  // this thread fetches 16-byte piece `seg` of rows r0, r0 + 8, ...
+    const float* qv = Qp + (size_t)q * ld;
+    f32x4 nxt[16];
+    float nq = 0.f;
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nxt[i] = *reinterpret_cast<const f32x4*>(X + (size_t)rowid[r0 + 8 * i] * ld + ch * 64 + seg * 4);
+        if (lane < 64) nq = qv[ch * 64 + lane];
+    };
+    fetch(0);
+    float acc = 0.f;
+    const int nch = ld >> 6;
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();  // everyone is done with the previous tile
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(tile + (r0 + 8 * i) * RR_STRIDE + seg * 4) = nxt[i];
+        if (lane < 64) qch[lane] = nq;
+        __syncthreads();
+        if (ch + 1 < nch) fetch(ch + 1);
+        const float* xr = tile + lane * RR_STRIDE;
+#pragma unroll
+        for (int t = 0; t < 64; t += 16) {
             f32x4 xa[4], qa[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                xa[g] = *reinterpret_cast<const f32x4*>(x + t + 4 * g);
-                qa[g] = *reinterpret_cast<const f32x4*>(qv + t + 4 * g);
+                xa[g] = *reinterpret_cast<const f32x4*>(xr + t + 4 * g);
+                qa[g] = *reinterpret_cast<const f32x4*>(qch + t + 4 * g);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc = fmaf(xa[g][c], qa[g][c], acc);
         }
+    }
+    uint64_t ek = SC_KEY_MAX;
+    if (ck != SC_KEY_MAX) {
+        const uint32_t row = (uint32_t)ck;
         ek = sc_make_key<METRIC>(sc_score<METRIC>(acc, xnorm[row], qnorm[q]), perm ? perm[row] : row);  // ties: reported row id
     }
     keys[lane] = ek;
