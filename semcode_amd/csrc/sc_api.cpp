@@ -566,7 +566,7 @@ static sc_status ensure_shadow(sc_index* ix) {
 }
 
 static const int BATCH_CAP = 4096;        // survivors kept per query and phase
-static const int64_t PHASE0_ROWS = 1024;  // first phase; each next phase covers 4x more rows
+static const int64_t PHASE0_ROWS = 256;   // first phase (every row of it survives, and selection is quadratic in the survivors); each next phase covers 4x more rows
 
 static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
