@@ -233,6 +233,10 @@ sc_status sc_index_search_dev(sc_index* ix, const float* q_dev, int32_t Q, int32
  * searches with Q * nprobe < nlist probe only the nprobe nearest lists (approximate, like the reference);
  * larger batches keep using the exhaustive paths, whose results are a superset in quality. */
 sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed);
+/* Persistence of a trained index (the `ivf.*` files of the on-disk collection): the list of every row in insertion order
+ * (out [rows] int32), and the inverse -- install centroids [nlist, dim] + that list without running k-means. */
+sc_status sc_index_ivf_assignments(sc_index* ix, int32_t* out);
+sc_status sc_index_set_ivf(sc_index* ix, const float* centroids, const int32_t* assign, int32_t nlist);
 /* nlist actually trained (0 = untrained), centroids [nlist, dim] and list sizes [nlist] (either may be NULL). */
 sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* centroids, int64_t* list_sizes);
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "sc_index_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_search_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_index_train": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
+    "sc_index_ivf_assignments": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "sc_index_set_ivf": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "sc_index_ivf_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -316,6 +318,20 @@ class Index:
         sizes = np.empty((n.value,), dtype=np.int64)
         _check(lib().sc_index_ivf_info(self.handle, C.byref(n), cent.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p)))
         return {"nlist": n.value, "centroids": cent, "list_sizes": sizes}
+
+    def ivf_assignments(self) -> np.ndarray:
+        """List of every row, insertion order (int32 [rows]); the index must be trained."""
+        out = np.empty(len(self), dtype=np.int32)
+        _check(lib().sc_index_ivf_assignments(self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_ivf(self, centroids, assign) -> None:
+        """Install a saved IVF structure (centroids [nlist, dim], list of every row) without re-running k-means."""
+        c = _as_f32(centroids, self.dim)
+        a = np.ascontiguousarray(assign, dtype=np.int32)
+        if a.shape != (len(self),):
+            raise ValueError("assign must have one entry per stored row")
+        _check(lib().sc_index_set_ivf(self.handle, c.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), c.shape[0]))
 
     def set_search_mode(self, mode: str) -> None:
         """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (see sc_index_set_search_mode)."""

@@ -85,6 +85,53 @@ sc_status sc_ivf_untrain_locked(sc_index* ix) {
     return SC_OK;
 }
 
+// Given a quantizer already installed in ix->quant and the list of every row (insertion order), re-order the corpus list-major.
+static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, const std::vector<int32_t>& assign) {
+    hipStream_t s = ix->rt->stream;
+    const int64_t n = ix->n;
+    const int ld = ix->ld;
+    std::vector<int64_t> off((size_t)nlist + 1, 0);
+    for (int64_t i = 0; i < n; ++i) off[(size_t)assign[(size_t)i] + 1]++;
+    for (int c = 0; c < nlist; ++c) off[(size_t)c + 1] += off[(size_t)c];
+    std::vector<uint32_t> perm((size_t)n), inv((size_t)n);
+    {
+        std::vector<int64_t> cur(off.begin(), off.end() - 1);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t pos = cur[(size_t)assign[(size_t)i]]++;
+            perm[(size_t)pos] = (uint32_t)i;
+            inv[(size_t)i] = (uint32_t)pos;
+        }
+    }
+    float *nx = nullptr, *nn = nullptr;
+    hipError_t e = hipMalloc((void**)&nx, (size_t)ix->capacity * ld * sizeof(float));
+    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "train: hipMalloc list-major corpus failed: %s", hipGetErrorString(e));
+    e = hipMalloc((void**)&nn, (size_t)ix->capacity * sizeof(float));
+    if (e != hipSuccess) {
+        hipFree(nx);
+        return sc_fail(SC_ERR_NOMEM, "train: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    SC_HIP(hipMalloc((void**)&ix->perm, (size_t)n * 4));
+    SC_HIP(hipMalloc((void**)&ix->inv, (size_t)n * 4));
+    SC_HIP(hipMalloc((void**)&ix->list_off, (size_t)(nlist + 1) * 8));
+    SC_HIP(hipMemcpyAsync(ix->perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(ix->inv, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(ix->list_off, off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
+    sc_launch_permute_rows(ix->X, ix->xnorm, ix->perm, n, ld, nx, nn, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(s));
+    hipFree(ix->X);
+    hipFree(ix->xnorm);
+    ix->X = nx;
+    ix->xnorm = nn;
+    ix->inv_h.swap(inv);
+    ix->list_off_h.swap(off);
+    ix->nlist_trained = nlist;
+    ix->shadow_rows = 0;
+    ix->uncert_frac = -1.0;
+    ix->trained = true;
+    return SC_OK;
+}
+
 extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) {
     (void)seed;  // the build is deterministic; kept for ABI stability
     if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
@@ -218,46 +265,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
     }
     st = assign_rows(ix, all_tight, n, assign);
     if (st) return st;
-    std::vector<int64_t> off((size_t)nlist + 1, 0);
-    for (int64_t i = 0; i < n; ++i) off[(size_t)assign[(size_t)i] + 1]++;
-    for (int c = 0; c < nlist; ++c) off[(size_t)c + 1] += off[(size_t)c];
-    std::vector<uint32_t> perm((size_t)n), inv((size_t)n);
-    {
-        std::vector<int64_t> cur(off.begin(), off.end() - 1);
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t pos = cur[(size_t)assign[(size_t)i]]++;
-            perm[(size_t)pos] = (uint32_t)i;
-            inv[(size_t)i] = (uint32_t)pos;
-        }
-    }
-    float *nx = nullptr, *nn = nullptr;
-    hipError_t e = hipMalloc((void**)&nx, (size_t)ix->capacity * ld * sizeof(float));
-    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "train: hipMalloc list-major corpus failed: %s", hipGetErrorString(e));
-    e = hipMalloc((void**)&nn, (size_t)ix->capacity * sizeof(float));
-    if (e != hipSuccess) {
-        hipFree(nx);
-        return sc_fail(SC_ERR_NOMEM, "train: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    SC_HIP(hipMalloc((void**)&ix->perm, (size_t)n * 4));
-    SC_HIP(hipMalloc((void**)&ix->inv, (size_t)n * 4));
-    SC_HIP(hipMalloc((void**)&ix->list_off, (size_t)(nlist + 1) * 8));
-    SC_HIP(hipMemcpyAsync(ix->perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    SC_HIP(hipMemcpyAsync(ix->inv, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    SC_HIP(hipMemcpyAsync(ix->list_off, off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
-    sc_launch_permute_rows(ix->X, ix->xnorm, ix->perm, n, ld, nx, nn, s);
-    SC_HIP(hipGetLastError());
-    SC_HIP(hipStreamSynchronize(s));
-    hipFree(ix->X);
-    hipFree(ix->xnorm);
-    ix->X = nx;
-    ix->xnorm = nn;
-    ix->inv_h.swap(inv);
-    ix->list_off_h.swap(off);
-    ix->nlist_trained = nlist;
-    ix->shadow_rows = 0;
-    ix->uncert_frac = -1.0;
-    ix->trained = true;
-    return SC_OK;
+    return ivf_install_lists_locked(ix, nlist, assign);
 }
 
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe) {
@@ -502,6 +510,41 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;
     return SC_OK;
+}
+
+// List of every row, in insertion order (persistence: together with the centroids this restores the lists without k-means).
+extern "C" sc_status sc_index_ivf_assignments(sc_index* ix, int32_t* out) {
+    if (!ix || !out) return sc_fail(SC_ERR_INVALID, "sc_index_ivf_assignments: NULL argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->trained) return sc_fail(SC_ERR_STATE, "sc_index_ivf_assignments: the index is not trained");
+    for (int64_t i = 0; i < ix->n; ++i) {
+        const int64_t pos = ix->inv_h[(size_t)i];
+        const auto it = std::upper_bound(ix->list_off_h.begin(), ix->list_off_h.end(), pos);
+        out[i] = (int32_t)(it - ix->list_off_h.begin()) - 1;
+    }
+    return SC_OK;
+}
+
+// Install a previously trained IVF structure: centroids [nlist, dim] (tight f32) and the list of every row.
+extern "C" sc_status sc_index_set_ivf(sc_index* ix, const float* centroids, const int32_t* assign, int32_t nlist) {
+    if (!ix || !centroids || !assign || nlist < 1) return sc_fail(SC_ERR_INVALID, "sc_index_set_ivf: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->kind != SC_INDEX_IVF_FLAT) return sc_fail(SC_ERR_STATE, "sc_index_set_ivf: index kind is not IVF_FLAT");
+    if (ix->n < 1) return sc_fail(SC_ERR_STATE, "sc_index_set_ivf: the index is empty");
+    for (int64_t i = 0; i < ix->n; ++i)
+        if (assign[i] < 0 || assign[i] >= nlist) return sc_fail(SC_ERR_INVALID, "sc_index_set_ivf: assign[%lld] = %d outside [0,%d)", (long long)i, assign[i], nlist);
+    SC_HIP(hipSetDevice(ix->rt->device));
+    sc_status st = sc_ivf_untrain_locked(ix);
+    if (st) return st;
+    if (ix->quant) {
+        sc_index_destroy(ix->quant);
+        ix->quant = nullptr;
+    }
+    st = sc_index_create(ix->rt, ix->dim, assign_metric(ix->metric), SC_INDEX_FLAT, 0, 0, &ix->quant);
+    if (st) return st;
+    st = sc_index_add(ix->quant, centroids, nlist);
+    if (st) return st;
+    return ivf_install_lists_locked(ix, nlist, std::vector<int32_t>(assign, assign + ix->n));
 }
 
 // Centroids (tight [nlist, dim]) and list sizes back to the host (tests, persistence).

@@ -344,7 +344,8 @@ class MilvusVectorStore:
     # ------------------------------------------------------------------ persistence (replaces Milvus' volume, docker-compose.yml:13-14)
     def save(self, path: "str | Path") -> None:
         """Write the collection to `path/` : manifest.json, vectors.f32 (row-major [rows, dim]), columns.jsonl
-        (id, repo, path, language, text, metadata per row).  Written to a temporary directory and renamed."""
+        (id, repo, path, language, text, metadata per row) and, when the IVF_FLAT lists are built, ivf_centroids.f32
+        ([nlist, dim]) + ivf_assign.i32 (list of every row).  Written to a temporary directory and renamed."""
         if self._collection is None:
             raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
         path = Path(path)
@@ -364,6 +365,11 @@ class MilvusVectorStore:
                                         "text": self._texts[r], "metadata": self._metadata[r]}, ensure_ascii=False) + "\n")
             manifest = {"format": "semcode_amd.collection.v1", "collection_name": self.collection_name, "dim": self.dim, "rows": n,
                         "metric": self.metric, "index_type": self.index_type, "nlist": self.nlist, "nprobe": self.nprobe}
+            ivf = self._collection.ivf_info() if (not self._needs_train and hasattr(self._collection, "ivf_info")) else None
+            if ivf and ivf.get("nlist", 0) > 0 and hasattr(self._collection, "ivf_assignments"):
+                np.ascontiguousarray(ivf["centroids"], dtype="<f4").tofile(tmp / "ivf_centroids.f32")
+                np.ascontiguousarray(self._collection.ivf_assignments(), dtype="<i4").tofile(tmp / "ivf_assign.i32")
+                manifest["ivf_trained_nlist"] = int(ivf["nlist"])
             (tmp / "manifest.json").write_text(json.dumps(manifest, indent=1))
         if path.exists():
             shutil.rmtree(path)
@@ -399,6 +405,15 @@ class MilvusVectorStore:
             if len(self._ids) != n:
                 raise ValueError(f"{path}: columns.jsonl holds {len(self._ids)} rows, manifest says {n}")
             self._needs_train = True
+            # the saved lists are reused as they are (no k-means) when they fit this collection's index parameters
+            tn = int(manifest.get("ivf_trained_nlist", 0))
+            if (tn > 0 and n > 0 and self.index_type == "IVF_FLAT" and manifest.get("metric") == self.metric and hasattr(self._collection, "set_ivf")
+                    and (path / "ivf_centroids.f32").exists() and (path / "ivf_assign.i32").exists()):
+                cent = np.fromfile(path / "ivf_centroids.f32", dtype="<f4")
+                assign = np.fromfile(path / "ivf_assign.i32", dtype="<i4")
+                if cent.size == tn * self.dim and assign.size == n:
+                    self._collection.set_ivf(cent.reshape(tn, self.dim), assign)
+                    self._needs_train = False
 
     def __iter__(self) -> Iterator:  # pragma: no cover - convenience
         return iter(self._ids)

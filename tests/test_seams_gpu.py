@@ -101,6 +101,38 @@ def test_store_save_load_round_trip_on_device(rt, tmp_path):
     a.close(); b.close()
 
 
+def test_store_save_load_keeps_trained_ivf_lists(rt, tmp_path):
+    """A saved collection whose IVF_FLAT lists were built comes back with the same lists (no k-means on load): identical
+    centroids, list sizes and probe results (the ivf.* files of the on-disk format)."""
+    rng = np.random.default_rng(1)
+    centers = rng.standard_normal((16, 64)).astype(np.float32) * 3
+    vecs = (centers[rng.integers(0, 16, size=6000)] + rng.standard_normal((6000, 64)).astype(np.float32)).astype(np.float32)
+    meta = {"repo": "r", "path": "p", "language": "py", "start_line": 1, "end_line": 2, "symbol": None}
+    a = MilvusVectorStore(dim=64, metric="L2", index_type="IVF_FLAT", nlist=32, nprobe=4, runtime=rt)
+    a.connect()
+    a.upsert_arrays([f"k{i}" for i in range(6000)], vecs, ["t"] * 6000, [meta] * 6000)
+    q = vecs[:5] + 0.01
+    da, ra = a.search_batch(q, top_k=5)  # builds the lists (6000 >= 39 * 32) and probes them
+    assert a._collection.last_search_stats()["path"] == "ivf"
+    a.save(tmp_path / "col")
+    assert (tmp_path / "col" / "ivf_centroids.f32").exists() and (tmp_path / "col" / "ivf_assign.i32").exists()
+    b = MilvusVectorStore(dim=64, metric="L2", index_type="IVF_FLAT", nlist=32, nprobe=4, runtime=rt)
+    b.connect()
+    b.load(tmp_path / "col")
+    assert b._needs_train is False
+    ia, ib = a._collection.ivf_info(), b._collection.ivf_info()
+    assert ib["nlist"] == 32 and np.array_equal(ia["centroids"].view(np.uint32), ib["centroids"].view(np.uint32))
+    assert np.array_equal(ia["list_sizes"], ib["list_sizes"]) and np.array_equal(a._collection.ivf_assignments(), b._collection.ivf_assignments())
+    db, rb = b.search_batch(q, top_k=5)
+    assert b._collection.last_search_stats()["path"] == "ivf"
+    assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    assert np.array_equal(b._collection.get_rows(0, 6000), vecs)
+    # an upsert after load invalidates the lists as usual; they are rebuilt before the next search
+    b.upsert_arrays(["k0"], vecs[1:2], ["t"], [meta])
+    assert b._needs_train is True
+    a.close(); b.close()
+
+
 def test_provider_with_vocab_uses_native_tokenizer(rt, tmp_path):
     words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "def", "return", "x", "y", "f", "(", ")", ":", "+", "1", "##1", "caf", "##e"]
     vocab = tmp_path / "vocab.txt"
