@@ -237,6 +237,10 @@ sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed);
  * (out [rows] int32), and the inverse -- install centroids [nlist, dim] + that list without running k-means. */
 sc_status sc_index_ivf_assignments(sc_index* ix, int32_t* out);
 sc_status sc_index_set_ivf(sc_index* ix, const float* centroids, const int32_t* assign, int32_t nlist);
+/* Build the lists for given centroids [nlist, dim] without k-means (every row to its nearest centroid).  Multi-GPU IVF_FLAT: one
+ * rank trains and broadcasts its centroids, every rank calls this on its shard; the merged probe results then equal those of one
+ * index over the whole corpus with these centroids. */
+sc_status sc_index_assign_lists(sc_index* ix, const float* centroids, int32_t nlist);
 /* nlist actually trained (0 = untrained), centroids [nlist, dim] and list sizes [nlist] (either may be NULL). */
 sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* centroids, int64_t* list_sizes);
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "sc_index_train": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64]),
     "sc_index_ivf_assignments": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "sc_index_set_ivf": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "sc_index_assign_lists": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "sc_index_ivf_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -332,6 +333,12 @@ class Index:
         if a.shape != (len(self),):
             raise ValueError("assign must have one entry per stored row")
         _check(lib().sc_index_set_ivf(self.handle, c.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), c.shape[0]))
+
+    def assign_lists(self, centroids) -> None:
+        """Build the IVF lists for given centroids [nlist, dim] (no k-means): what every rank of a sharded collection does
+        with the centroids one rank trained."""
+        c = _as_f32(centroids, self.dim)
+        _check(lib().sc_index_assign_lists(self.handle, c.ctypes.data_as(C.c_void_p), c.shape[0]))
 
     def set_search_mode(self, mode: str) -> None:
         """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (see sc_index_set_search_mode)."""

@@ -132,6 +132,26 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, const std::ve
     return SC_OK;
 }
 
+// Quantizer installed in ix->quant: assign every stored row to its nearest centroid and re-order the corpus list-major.
+static sc_status ivf_assign_all_and_install_locked(sc_index* ix, int nlist) {
+    hipStream_t s = ix->rt->stream;
+    const int64_t n = ix->n;
+    struct Dev {
+        void* p = nullptr;
+        ~Dev() { hipFree(p); }
+    } d_tight;
+    const float* all_tight = ix->X;
+    if (ix->ld != ix->dim) {
+        SC_HIP(hipMalloc(&d_tight.p, (size_t)n * ix->dim * 4));
+        sc_launch_gather_rows(ix->X, ix->ld, 0, n, ix->dim, (float*)d_tight.p, s);
+        all_tight = (const float*)d_tight.p;
+    }
+    std::vector<int32_t> assign;
+    sc_status st = assign_rows(ix, all_tight, n, assign);
+    if (st) return st;
+    return ivf_install_lists_locked(ix, nlist, assign);
+}
+
 extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) {
     (void)seed;  // the build is deterministic; kept for ABI stability
     if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
@@ -256,16 +276,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
         set_centroids((const float*)d_cnew.p);
     }
 
-    // ---- assign every row, build list-major order
-    const float* all_tight = ix->X;
-    if (ld != dim) {
-        SC_HIP(hipMalloc(&d_tight.p, (size_t)n * dim * 4));
-        sc_launch_gather_rows(ix->X, ld, 0, n, dim, (float*)d_tight.p, s);
-        all_tight = (const float*)d_tight.p;
-    }
-    st = assign_rows(ix, all_tight, n, assign);
-    if (st) return st;
-    return ivf_install_lists_locked(ix, nlist, assign);
+    return ivf_assign_all_and_install_locked(ix, nlist);
 }
 
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe) {
@@ -523,6 +534,28 @@ extern "C" sc_status sc_index_ivf_assignments(sc_index* ix, int32_t* out) {
         out[i] = (int32_t)(it - ix->list_off_h.begin()) - 1;
     }
     return SC_OK;
+}
+
+// Build the lists for GIVEN centroids (no k-means): every row goes to its nearest centroid under the assignment metric.  Multi-GPU
+// IVF: one rank trains, broadcasts its centroids, every rank calls this on its shard -- probing then means the same lists on every
+// shard, and the merged result equals that of one index over the whole corpus with these centroids.
+extern "C" sc_status sc_index_assign_lists(sc_index* ix, const float* centroids, int32_t nlist) {
+    if (!ix || !centroids || nlist < 1) return sc_fail(SC_ERR_INVALID, "sc_index_assign_lists: bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->kind != SC_INDEX_IVF_FLAT) return sc_fail(SC_ERR_STATE, "sc_index_assign_lists: index kind is not IVF_FLAT");
+    if (ix->n < 1) return sc_fail(SC_ERR_STATE, "sc_index_assign_lists: the index is empty");
+    SC_HIP(hipSetDevice(ix->rt->device));
+    sc_status st = sc_ivf_untrain_locked(ix);
+    if (st) return st;
+    if (ix->quant) {
+        sc_index_destroy(ix->quant);
+        ix->quant = nullptr;
+    }
+    st = sc_index_create(ix->rt, ix->dim, assign_metric(ix->metric), SC_INDEX_FLAT, 0, 0, &ix->quant);
+    if (st) return st;
+    st = sc_index_add(ix->quant, centroids, nlist);
+    if (st) return st;
+    return ivf_assign_all_and_install_locked(ix, nlist);
 }
 
 // Install a previously trained IVF structure: centroids [nlist, dim] (tight f32) and the list of every row.

@@ -157,3 +157,35 @@ def test_clustered_synthetic_fill_matches_restatement(rt):
     want = orc.synth_clustered(2000, 96, seed=5, nclusters=37, spread=0.5, first_row=1000)
     assert np.array_equal(bits(got), bits(want))
     ix.close()
+
+
+def test_sharded_ivf_with_shared_centroids_equals_one_index(rt):
+    """Multi-GPU IVF_FLAT, two logical shards on one device: shard 0 trains, shard 1 builds its lists for
+    shard 0's centroids (sc_index_assign_lists = what the other ranks do after the broadcast); the merge of the two shards' probe
+    results equals the probe result of ONE index over all rows with the same centroids -- the result does not depend on sharding."""
+    X, centers = clustered(24_000, 64, 30, seed=21)
+    rng = np.random.default_rng(22)
+    Q = (centers[rng.integers(0, 30, size=48)] + 0.3 * rng.standard_normal((48, 64))).astype(np.float32)
+    a = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=32, row_base=0)
+    b = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=32, row_base=12_000)
+    a.add(X[:12_000])
+    b.add(X[12_000:])
+    a.train(niter=6)
+    cent = a.ivf_info()["centroids"]
+    b.assign_lists(cent)
+    assert np.array_equal(bits(b.ivf_info()["centroids"]), bits(cent))
+    whole = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=32)
+    whole.add(X)
+    whole.assign_lists(cent)
+    assert int(whole.ivf_info()["list_sizes"].sum()) == 24_000
+    assert np.array_equal(whole.ivf_info()["list_sizes"], a.ivf_info()["list_sizes"] + b.ivf_info()["list_sizes"])
+    for mode, nq in (("ivf", 3), ("ivf_listmajor", 48)):
+        for ix in (a, b, whole):
+            ix.set_search_mode(mode)
+        da, ra = a.search(Q[:nq], k=10, nprobe=4)
+        db, rb = b.search(Q[:nq], k=10, nprobe=4)
+        dw, rw = whole.search(Q[:nq], k=10, nprobe=4)
+        md, mr = _native.topk_merge_host("L2", np.stack([da, db]), np.stack([ra, rb]))
+        assert np.array_equal(mr, rw) and np.array_equal(bits(md), bits(dw)), mode
+    for ix in (a, b, whole):
+        ix.close()
