@@ -1,6 +1,6 @@
 """Generate the committed golden vectors under tests/golden/.  TEST INFRASTRUCTURE ONLY.
 
-    python -m oracle.gen_fixtures [knn] [synth] [md5] [encoder]
+    python -m oracle.gen_fixtures [knn] [synth] [md5] [encoder] [ivf]
 
 The reference itself cannot be imported here (langchain / pymilvus absent) and
 its tests hold no numerical vector for this path, so these fixtures are produced by independent
@@ -10,6 +10,7 @@ implementations available in the container:
   * chunk_id   : hashlib.md5 known answers for IndexerService._make_chunk_id
                  (reference src/semcode/services/indexer.py:185-188)
   * encoder_*  : transformers' local BertModel class with seeded random weights (see gen_encoder())
+  * ivf_*      : the deterministic IVF_FLAT build rule itself (a regression lock, see gen_ivf(): nothing independent exists)
 """
 from __future__ import annotations
 
@@ -45,6 +46,27 @@ def gen_knn() -> None:
         out[f"{metric}_score64"] = s64
     np.savez_compressed(GOLDEN / "knn_4096x64.npz", **out)
     print("wrote knn_4096x64.npz")
+
+
+def gen_ivf() -> None:
+    """IVF_FLAT build + probe of the deterministic build rule (oracle/ivf_oracle.py restates semcode_amd/csrc/sc_ivf.cpp) on the kNN
+    fixture's rows.  There is nothing independent to generate these from (Milvus' k-means is random and absent): the file LOCKS
+    the rule -- sampling, initialisation, Lloyd + re-seeding, assignment metric, probe order -- against silent change, and both the
+    CPU restatement and the GPU build are checked against it."""
+    from .ivf_oracle import IvfOracle
+
+    d = np.load(GOLDEN / "knn_4096x64.npz")
+    X, Q = d["X"], d["Q"]
+    out = {}
+    for metric in ("IP", "L2", "COSINE"):
+        o = IvfOracle(X, metric, nlist=16, niter=6)
+        dist, rows = o.search(Q, 10, 4)
+        out[f"{metric}_centroids"] = o.centroids
+        out[f"{metric}_assign"] = o.assign.astype(np.int32)
+        out[f"{metric}_rows"] = rows
+        out[f"{metric}_dist"] = dist
+    np.savez_compressed(GOLDEN / "ivf_4096x64.npz", **out)
+    print("wrote ivf_4096x64.npz")
 
 
 M64 = (1 << 64) - 1
@@ -92,9 +114,11 @@ def gen_md5() -> None:
 
 def main(argv: list[str]) -> None:
     GOLDEN.mkdir(parents=True, exist_ok=True)
-    what = set(argv) or {"knn", "synth", "md5", "encoder"}
+    what = set(argv) or {"knn", "synth", "md5", "encoder", "ivf"}
     if "knn" in what:
         gen_knn()
+    if "ivf" in what:
+        gen_ivf()
     if "synth" in what:
         gen_synth()
     if "md5" in what:

@@ -189,3 +189,21 @@ def test_sharded_ivf_with_shared_centroids_equals_one_index(rt):
         assert np.array_equal(mr, rw) and np.array_equal(bits(md), bits(dw)), mode
     for ix in (a, b, whole):
         ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+def test_gpu_build_matches_committed_build(rt, golden, metric):
+    """The device build against the committed lock of the build rule (tests/golden/ivf_4096x64.npz): centroids bit for bit, the
+    same list of every row, the same probe results."""
+    d = np.load(golden / "knn_4096x64.npz")
+    g = np.load(golden / "ivf_4096x64.npz")
+    ix = _native.Index(rt, 64, metric=metric, kind="IVF_FLAT", nlist=16)
+    ix.add(d["X"])
+    ix.train(niter=6)
+    assert np.array_equal(bits(ix.ivf_info()["centroids"]), bits(g[f"{metric}_centroids"]))
+    assert np.array_equal(ix.ivf_assignments(), g[f"{metric}_assign"])
+    for mode in ("ivf", "ivf_listmajor"):
+        ix.set_search_mode(mode)
+        dist, rows = ix.search(d["Q"], k=10, nprobe=4)
+        assert np.array_equal(rows, g[f"{metric}_rows"]) and np.array_equal(bits(dist), bits(g[f"{metric}_dist"])), mode
+    ix.close()

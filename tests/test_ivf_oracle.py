@@ -38,3 +38,17 @@ def test_lists_partition_rows_and_recall_grows_with_nprobe():
         _, r = ivf.search(Q, 10, nprobe)
         recalls.append(np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(r.tolist(), exact.tolist())]))
     assert recalls[0] <= recalls[1] <= recalls[2] and recalls[2] == 1.0 and recalls[1] > 0.8
+
+
+def test_ivf_restatement_matches_committed_build(golden):
+    """tests/golden/ivf_4096x64.npz locks the deterministic build rule (generator: oracle/gen_fixtures.py gen_ivf): same centroids
+    bit for bit, same lists, same probe results -- a change of sampling, initialisation, re-seeding or probe order shows up here
+    and in tests/test_ivf_gpu.py::test_gpu_build_matches_committed_build."""
+    d = np.load(golden / "knn_4096x64.npz")
+    g = np.load(golden / "ivf_4096x64.npz")
+    for metric in ("IP", "L2", "COSINE"):
+        o = IvfOracle(d["X"], metric, nlist=16, niter=6)
+        assert np.array_equal(o.centroids.view(np.uint32), g[f"{metric}_centroids"].view(np.uint32))
+        assert np.array_equal(o.assign, g[f"{metric}_assign"])
+        dist, rows = o.search(d["Q"], 10, 4)
+        assert np.array_equal(rows, g[f"{metric}_rows"]) and np.array_equal(dist.view(np.uint32), g[f"{metric}_dist"].view(np.uint32))
