@@ -10,6 +10,7 @@
 #define SC_KEY_MAX 0xFFFFFFFFFFFFFFFFull
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -68,7 +69,9 @@ void sc_launch_gather_rows(const float* src, int ld, int64_t first, int64_t n, i
 
 struct ScanPlan {
     int qt;          // queries per group (<=16)
+    int qstream;     // 0: queries resident in LDS; else streamed per k-chunk through a shared LDS ring that many stages deep
     int groups;      // ceil(Q / qt)
+    int gstride;     // slots per group in qmap / partial when that differs from qt (0 = qt)
     int nwg;         // workgroups per group (grid.x)
     int cap;         // per-(wave,query) candidate capacity
     int lists;       // partial lists per query = nwg * 4

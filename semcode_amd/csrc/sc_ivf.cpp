@@ -444,31 +444,53 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     std::vector<int32_t> src((size_t)Q * L, -1), qmap;
     std::vector<int> sb;
     std::vector<int64_t> sr;
-    int G = 0;
-    for (int l = 0; l < nlist; ++l) {
-        const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
-        const int m = start[(size_t)l + 1] - start[(size_t)l];
-        if (m == 0 || end <= first) continue;  // nobody probes it / empty list
-        const int parts = (int)((end - first + target - 1) / target);
-        for (int c = 0; c < m; c += qt) {
-            for (int part = 0; part < parts; ++part) {
-                const int64_t p0 = first + (int64_t)part * target, p1 = std::min(end, p0 + target);
-                for (int sl = 0; sl < qt; ++sl) {
-                    if (c + sl < m) {
-                        const int32_t pair = pair_of[(size_t)start[(size_t)l] + c + sl];
-                        const int q = pair / nprobe, j = pair - q * nprobe;
-                        qmap.push_back(q);
-                        src[(size_t)q * L + (size_t)j * maxparts + part] = G * qt + sl;
-                    } else {
-                        qmap.push_back(-1);
-                    }
+    // With the streamed-query scan (long rows, qt = 16) a group of few queries is still better off on the resident variant,
+    // which streams ~30 % faster: groups are numbered in two classes -- first those with more queries than fit resident
+    // (qt_res), then the small ones -- and each class gets its own launch over the one (group, slot) numbering of stride qt.
+    ScanPlan plan_res = plan;
+    if (plan.qstream && !sc_scan_exact_plan(ix->ld, 16, k, rt->cus, &plan_res, 16, 1)) plan_res = plan;
+    int qt_res = plan_res.qstream ? qt : std::min(qt, plan_res.qt);
+    if (const char* e = getenv("SC_SCAN_QSTREAM"))
+        if (plan.qstream && e[0] != '0') qt_res = 0;  // forced: every group on the streamed variant (tests, A/B)
+    // Within a class the longest parts go first: one workgroup streams one group, and a 100 MB part that starts in the last
+    // round would leave the other CUs idle for its whole length (stable sort: the numbering stays deterministic).
+    struct GroupDesc { int l, c, part; int64_t p0, p1; };
+    std::vector<GroupDesc> descs;
+    int G = 0, G_big = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+        if (cls == 1) G_big = G;
+        descs.clear();
+        for (int l = 0; l < nlist; ++l) {
+            const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
+            const int m = start[(size_t)l + 1] - start[(size_t)l];
+            if (m == 0 || end <= first) continue;  // nobody probes it / empty list
+            const int parts = (int)((end - first + target - 1) / target);
+            for (int c = 0; c < m; c += qt) {
+                if ((std::min(qt, m - c) > qt_res) != (cls == 0)) continue;
+                for (int part = 0; part < parts; ++part) {
+                    const int64_t p0 = first + (int64_t)part * target;
+                    descs.push_back({l, c, part, p0, std::min(end, p0 + target)});
                 }
-                sb.push_back(0);
-                sb.push_back((int)((p1 - p0 + 15) >> 4));
-                sr.push_back(p0);
-                sr.push_back(p1);
-                ++G;
             }
+        }
+        std::stable_sort(descs.begin(), descs.end(), [](const GroupDesc& x, const GroupDesc& y) { return x.p1 - x.p0 > y.p1 - y.p0; });
+        for (const GroupDesc& d : descs) {
+            const int m = start[(size_t)d.l + 1] - start[(size_t)d.l];
+            for (int sl = 0; sl < qt; ++sl) {
+                if (d.c + sl < m) {
+                    const int32_t pair = pair_of[(size_t)start[(size_t)d.l] + d.c + sl];
+                    const int q = pair / nprobe, j = pair - q * nprobe;
+                    qmap.push_back(q);
+                    src[(size_t)q * L + (size_t)j * maxparts + d.part] = G * qt + sl;
+                } else {
+                    qmap.push_back(-1);
+                }
+            }
+            sb.push_back(0);
+            sb.push_back((int)((d.p1 - d.p0 + 15) >> 4));
+            sr.push_back(d.p0);
+            sr.push_back(d.p1);
+            ++G;
         }
     }
     const double t_plan = since();
@@ -495,12 +517,14 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     // 4. one workgroup per group (grid.y is limited to 65535 groups per launch)
     hipEvent_t e0, e1;
     sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-    for (int g0 = 0; g0 < G; g0 += 65535) {
-        const int gn = std::min(65535, G - g0);
-        ScanPlan p = plan;
+    for (int cls = 0; cls < 2; ++cls)
+      for (int g0 = cls ? G_big : 0, hi = cls ? G : G_big; g0 < hi; g0 += 65535) {
+        const int gn = std::min(65535, hi - g0);
+        ScanPlan p = cls ? plan_res : plan;
         p.groups = gn;
         p.nwg = 1;
         p.lists = 1;
+        p.gstride = qt;
         sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, gn * qt, k, p,
                              ix->partial + (size_t)g0 * qt * k, ix->perm, (const int*)(b + o_sb) + (size_t)g0 * 2,
                              (const int64_t*)(b + o_sr) + (size_t)g0 * 2, 1, s, (const int32_t*)(b + o_qmap) + (size_t)g0 * qt);
@@ -511,12 +535,16 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     SC_HIP(hipGetLastError());
     SC_HIP(hipStreamSynchronize(s));  // the host plan vectors go out of scope
     if (trace) {
-        double streamed = 0.0;
-        for (size_t g = 0; g < sr.size(); g += 2) streamed += (double)(sr[g + 1] - sr[g]);
+        double streamed = 0.0, streamed_big = 0.0;
+        for (size_t g = 0; g < sr.size(); g += 2) {
+            streamed += (double)(sr[g + 1] - sr[g]);
+            if ((int)(g / 2) < G_big) streamed_big += (double)(sr[g + 1] - sr[g]);
+        }
         streamed *= (double)ix->ld * 4.0;
+        streamed_big *= (double)ix->ld * 4.0;
         const double t_scan = since() - t_plan;
-        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d parts<=%d target=%lld rows | D2H of probes %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms = %.1f GB at %.2f TB/s\n",
-                Q, nprobe, qt, G, maxparts, (long long)target, t_probe, t_plan - t_probe, t_scan, streamed / 1e9, streamed / 1e9 / t_scan);
+        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d (%d = %.1f GB on streamed queries) parts<=%d target=%lld rows | D2H of probes %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms = %.1f GB at %.2f TB/s\n",
+                Q, nprobe, qt, G, plan.qstream ? G_big : 0, plan.qstream ? streamed_big / 1e9 : 0.0, maxparts, (long long)target, t_probe, t_plan - t_probe, t_scan, streamed / 1e9, streamed / 1e9 / t_scan);
     }
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;

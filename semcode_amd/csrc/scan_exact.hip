@@ -20,10 +20,19 @@
 //   * per tile each lane holds 4 scores of one query: threshold filter against the wave's running
 //     k-th best key, rare LDS append, rank-sort compaction when a candidate buffer fills;
 //   * at the end the workgroup merges its 4 waves' lists; topk_merge.hip reduces the per-workgroup lists.
+//
+// Streamed-query variant (QS = true), for rows so long that 16 resident queries no longer fit beside the ring (ld > ~1400:
+// 3 072-d vectors left room for 6, so a list wanted by 16 queries was streamed three times): the queries are not resident.
+// The four waves walk the k-chunks of their tiles in lock step and share a 4-deep ring of query stages (16 queries x 64
+// floats, the same XOR swizzle); wave w LDS-DMAs quarter w of every query stage from L2 (the query block is 16 x ld x 4 B and
+// stays cache resident), one raw s_barrier per stage publishes it (after the issuing wave's counted vmcnt) and frees the slot
+// the next request overwrites.  Same MFMA chain per (row, query), so results are bit-identical to the resident variant.
 #include "sc_common.h"
+#include <stdlib.h>
 
 #define SCAN_WAVES 4
 #define SCAN_NSTAGE 4
+#define SCAN_NORM_SLOTS 4
 #define SCAN_STAGE_BYTES 4096
 #define SCAN_NORM_BYTES 256
 #define SCAN_QPAD 8  // floats
@@ -60,17 +69,22 @@ struct ScanArgs {
     // optional: query slot -> row of Qp / qnorm (list-major probing gathers each group's queries); a group's valid slots
     // are a prefix, the first negative entry ends it.  NULL = identity.
     const int32_t* qmap;
+    // slots per group in qmap / partial (>= qt; 0 = qt): list-major probing runs groups of few queries on the resident variant
+    // and the others on the streamed one, with one numbering of (group, slot)
+    int gstride;
 };
 
 struct ScanLds {
     unsigned ring, norms, qs, qn, thr, cnt, cand, tmp, seg, total;
 };
-__host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int cap, int nprobe = 0) {
+// qstream: 0 = resident queries, else the number of ring stages of the streamed-query variant (SCAN_NSTAGE)
+__host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int cap, int nprobe = 0, int qstream = 0) {
+    const unsigned nst = qstream ? (unsigned)qstream : (unsigned)SCAN_NSTAGE;
     ScanLds L;
     unsigned o = 0;
-    L.ring = o; o += SCAN_WAVES * SCAN_NSTAGE * SCAN_STAGE_BYTES;
-    L.norms = o; o += SCAN_WAVES * SCAN_NSTAGE * SCAN_NORM_BYTES;
-    L.qs = o; o += (unsigned)qt * (unsigned)(ld + SCAN_QPAD) * 4u;
+    L.ring = o; o += SCAN_WAVES * nst * SCAN_STAGE_BYTES;
+    L.norms = o; o += SCAN_WAVES * SCAN_NORM_SLOTS * SCAN_NORM_BYTES;
+    L.qs = o; o += qstream ? nst * SCAN_STAGE_BYTES : (unsigned)qt * (unsigned)(ld + SCAN_QPAD) * 4u;
     L.qn = o; o += 64;
     L.thr = o; o += SCAN_WAVES * 16 * 8;
     L.cnt = o; o += SCAN_WAVES * 16 * 4;
@@ -99,19 +113,21 @@ static __device__ __forceinline__ void wave_compact(lds_u64p cand, lds_u64p tmp,
     }
 }
 
-template <int METRIC>
+template <int METRIC, int QS>
 __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
+    constexpr int NST = QS ? QS : SCAN_NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15;  // A row / B column (query slot)
     const int g = lane >> 4;    // k-group
-    const ScanLds L = scan_lds_layout(a.ld, a.qt, a.cap, a.seg_base ? a.nprobe : 0);
+    const ScanLds L = scan_lds_layout(a.ld, a.qt, a.cap, a.seg_base ? a.nprobe : 0, QS);
     const int ld = a.ld;
     const int spt = ld >> 6;  // stages per tile
     const int grp = blockIdx.y;
-    const int q0 = grp * a.qt;
+    const int gstride = a.gstride ? a.gstride : a.qt;
+    const int q0 = grp * gstride;
     int nq = min(a.qt, a.Q - q0);
     if (a.qmap) {
         int c = 0;
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     {
         const int qstride = ld + SCAN_QPAD;
         float* qs = reinterpret_cast<float*>(smem + L.qs);
-        for (int c = 0; c < a.qt; ++c) {
+        for (int c = 0; c < (QS ? 0 : a.qt); ++c) {
             const bool have = c < nq;
             const int qrow = a.qmap ? (have ? a.qmap[q0 + c] : 0) : q0 + (have ? c : 0);
             const float* src = a.Qp + (int64_t)qrow * ld;
@@ -157,10 +173,13 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     if (t1 > total_tiles) t1 = total_tiles;
     int ntiles = 0;
     if (t0 + w < t1) ntiles = (int)((t1 - (t0 + w) + SCAN_WAVES - 1) / SCAN_WAVES);
-    const int total_stages = ntiles * spt;
+    // QS: every wave runs the stage count of wave 0 (the barrier and the shared query ring need all four); a wave past its
+    // last tile streams clamped rows and drops the scores
+    const int max_tiles = t0 < t1 ? (int)((t1 - t0 + SCAN_WAVES - 1) / SCAN_WAVES) : 0;
+    const int total_stages = (QS ? max_tiles : ntiles) * spt;
 
-    char* ring = smem + L.ring + w * (SCAN_NSTAGE * SCAN_STAGE_BYTES);
-    char* nrm = smem + L.norms + w * (SCAN_NSTAGE * SCAN_NORM_BYTES);
+    char* ring = smem + L.ring + w * (NST * SCAN_STAGE_BYTES);
+    char* nrm = smem + L.norms + w * (SCAN_NORM_SLOTS * SCAN_NORM_BYTES);
     const char* qsb = smem + L.qs + (size_t)(r16 < a.qt ? r16 : a.qt - 1) * (size_t)(ld + SCAN_QPAD) * 4u + (size_t)g * 16u;
     lds_u64p thr_w = (lds_u64p)(smem + L.thr) + w * 16;
     lds_u32p cnt_w = (lds_u32p)(smem + L.cnt) + w * 16;
@@ -182,19 +201,23 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     };
     int iss_j = 0, con_j = 0;
     // issue side: (tile ordinal, k-chunk) of the next stage to request
-    int iss = 0, iss_tile = 0, iss_kc = 0;
+    int iss = 0, iss_tile = 0, iss_kc = 0, iss_slot = 0;
     // per-lane source geometry of one LDS-DMA piece: row-in-piece = lane>>4, slot = lane&15
     const int prow = lane >> 4, pslot = lane & 15;
 
     auto issue_stage = [&]() {
         int64_t row0, tlast;
         tile_span(t0 + w + (int64_t)iss_tile * SCAN_WAVES, iss_j, row0, tlast);
-        const int slot = iss & (SCAN_NSTAGE - 1);
+        const int slot = iss_slot;
+        if (++iss_slot == NST) iss_slot = 0;
         if (iss_kc == 0) {  // tile norms first: older than the tile's data in the vmcnt queue
             int64_t rr = row0 + r16;
             rr = rr > tlast ? tlast : rr;
-            __builtin_amdgcn_global_load_lds((gbl_vptr)(a.xnorm + rr), (lds_vptr)(nrm + (iss_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES),
-                                             4, 0, 0);
+            // one dword per lane: lanes 0-15 fetch the 16 row norms, lanes 16-31 the 16 reported row ids when the storage is
+            // permuted (list-major IVF) -- the candidate path then never touches global memory (a lookup there cost a full
+            // round trip with the ring drained, several times per tile while the thresholds are still loose)
+            const float* nsrc = (a.perm && (lane & 48) == 16) ? reinterpret_cast<const float*>(a.perm + rr) : a.xnorm + rr;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)nsrc, (lds_vptr)(nrm + (iss_tile & (SCAN_NORM_SLOTS - 1)) * SCAN_NORM_BYTES), 4, 0, 0);
         }
         char* dst = ring + slot * SCAN_STAGE_BYTES;
 #pragma unroll
@@ -208,49 +231,97 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         ++iss;
         if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
     };
+    // QS: this wave's quarter (queries 4w .. 4w+3) of the query stage for k-chunk qiss_kc -> shared ring slot qiss & 3
+    int qiss = 0, qiss_kc = 0, qiss_slot = 0;
+    const float* qsrc = a.Qp;
+    if (QS) {
+        const int c = 4 * w + prow;
+        const int cc = c < nq ? c : 0;
+        const int qrow = nq > 0 ? (a.qmap ? a.qmap[q0 + cc] : q0 + cc) : 0;
+        qsrc = a.Qp + (int64_t)qrow * ld + ((pslot ^ c) << 2);
+    }
+    char* qring = smem + L.qs;
+    auto issue_q = [&]() {
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc + (qiss_kc << 6)),
+                                         (lds_vptr)(qring + qiss_slot * SCAN_STAGE_BYTES + w * 1024), 16, 0, 0);
+        if (++qiss_slot == NST) qiss_slot = 0;
+        ++qiss;
+        if (++qiss_kc == spt) qiss_kc = 0;
+    };
 
 #pragma unroll 1
-    for (int j = 0; j < SCAN_NSTAGE - 1; ++j)
-        if (iss < total_stages) issue_stage();
+    for (int j = 0; j < NST - 1; ++j)
+        if (iss < total_stages) {
+            issue_stage();
+            if (QS) issue_q();
+        }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int con_tile = 0, con_kc = 0;
+    int con_tile = 0, con_kc = 0, con_slot = 0;
 #pragma unroll 1
     for (int si = 0; si < total_stages; ++si) {
         if (iss < total_stages) issue_stage();
         // younger stages in flight behind stage si: each is >= 4 LDS-DMA instructions
         const int pend = iss - si - 1;
-        if (pend >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (pend == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (pend == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        const char* st = ring + (si & (SCAN_NSTAGE - 1)) * SCAN_STAGE_BYTES + r16 * 256;
-        const char* qb = qsb + (size_t)con_kc * 256u;
+        if (!QS) {
+            if (pend >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (pend == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (pend == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // queue behind q(si), oldest first: rows(si+1) q(si+1) ... rows(si+NST-2) q(si+NST-2) rows(si+NST-1); the query piece
+            // of stage si+NST-1 is requested only after the barrier below (its slot was read in stage si-1 by all waves).
+            // pend = min(stages left, NST-1) row stages of 4 instructions, min(stages left, NST-2) query pieces
+            const int cnt = 4 * pend + (pend < NST - 2 ? pend : NST - 2);
+            switch (cnt) {
+                case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        }
+        // this wave's row fragments need only its own counted wait: in the streamed variant they are requested BEFORE the
+        // barrier, so their LDS latency runs under it
+        const char* st = ring + con_slot * SCAN_STAGE_BYTES + r16 * 256;
+        f32x4 av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4*>(st + (((4 * t + g) ^ r16) << 4));
+        if (QS) {
+            // raw barrier (__syncthreads() would drain vmcnt to 0 and with it the ring).  lgkmcnt(4): everything older than
+            // the four fragment reads above has returned -- in particular stage si-1's reads of the query slot that the
+            // request below overwrites (LDS returns in order; an outstanding scalar load only makes the wait stricter).
+            asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+            if (qiss < total_stages) issue_q();
+        }
+        const char* qb = QS ? qring + con_slot * SCAN_STAGE_BYTES + r16 * 256 : qsb + (size_t)con_kc * 256u;
+        if (++con_slot == NST) con_slot = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(st + (((4 * t + g) ^ r16) << 4));
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(qb + t * 64);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(QS ? qb + (((4 * t + g) ^ r16) << 4) : qb + t * 64);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][c], bv[c], acc, 0, 0, 0);
         }
 
-        if (++con_kc == spt) {
+        if (++con_kc == spt && con_tile >= ntiles) {  // QS only: a wave past its last tile
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            con_kc = 0;
+            ++con_tile;
+        } else if (con_kc == spt) {
             // ---- tile done: lane holds query r16, rows row0 + 4g + {0..3}
             int64_t row0, tlast;
             tile_span(t0 + w + (int64_t)con_tile * SCAN_WAVES, con_j, row0, tlast);
-            const f32x4 xn = *reinterpret_cast<const f32x4*>(nrm + (con_tile & (SCAN_NSTAGE - 1)) * SCAN_NORM_BYTES + g * 16);
+            const f32x4 xn = *reinterpret_cast<const f32x4*>(nrm + (con_tile & (SCAN_NORM_SLOTS - 1)) * SCAN_NORM_BYTES + g * 16);
+            const u32x4_t pid = *reinterpret_cast<const u32x4_t*>(nrm + (con_tile & (SCAN_NORM_SLOTS - 1)) * SCAN_NORM_BYTES + 64 + g * 16);
             const uint64_t thr = thr_w[r16];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int64_t row = row0 + 4 * g + c;
                 const float sc = sc_score<METRIC>(acc[c], xn[c], qn_mine);
-                uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
-                // with a permutation the low word is only known after a (rare-path) lookup: compare scores first
-                const bool cand = r16 < nq && row <= tlast && (a.perm ? (key >> 32) <= (thr >> 32) : key < thr);
-                if (cand && a.perm) {
-                    key = (key & 0xFFFFFFFF00000000ull) | a.perm[row];
-                }
+                const uint64_t key = sc_make_key<METRIC>(sc, a.perm ? pid[c] : (uint32_t)row);
+                const bool cand = r16 < nq && row <= tlast;
                 if (cand && key < thr) {
                     // inline asm: a compiler-visible LDS write here would get an s_waitcnt vmcnt(0) in front
                     // of it (it may alias the in-flight LDS-DMA as far as hipcc knows) and drain the ring.
@@ -277,7 +348,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     // keys are unique) and writes ONE sorted list: partial[grp][wg][slot][k]
     for (int c = 0; c < nq; ++c) wave_compact(cand_w + c * a.cap, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
     __syncthreads();
-    uint64_t* out = a.partial + ((size_t)grp * gridDim.x + blockIdx.x) * (size_t)a.qt * a.k;
+    uint64_t* out = a.partial + ((size_t)grp * gridDim.x + blockIdx.x) * (size_t)gstride * a.k;
     lds_u64p cand_all = (lds_u64p)(smem + L.cand);
     lds_u32p cnt_all = (lds_u32p)(smem + L.cnt);
     for (int c = 0; c < a.qt; ++c) {
@@ -306,18 +377,39 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
     if (ld <= 0 || (ld % SC_LD_ALIGN) != 0 || k < 1 || k > 1024 || Q < 1) return false;
     const int cap = ((k + 16 + 63) / 64) * 64;  // >= k + 16, multiple of 64
     const unsigned budget = 160 * 1024;
-    int qt = Q < 16 ? Q : 16;
+    const int want = Q < 16 ? Q : 16;
+    int qt = want;
     if (force_qt > 0 && force_qt < qt) qt = force_qt;
     while (qt >= 1 && scan_lds_layout(ld, qt, cap, nprobe).total > budget) --qt;
     if (qt < 1) return false;
+    // Streamed queries: when the resident layout cannot hold the queries of one pass (long rows), 16 slots with the query
+    // block streamed from L2 save whole passes over the rows (2M x 3072, 16 queries: 12.3 -> 5.2 ms).  The lock step costs
+    // ~20 % of the streaming rate (4.7 vs 5.9 TB/s; a 6-deep ring measured the same as 4), so it is used only when it saves a
+    // pass.  SC_SCAN_QSTREAM=0 forces the resident variant, anything else the streamed one wherever it fits (A/B runs, tests).
+    const bool fits = force_qt <= 0 && ld >= 128 && scan_lds_layout(ld, 16, cap, nprobe, SCAN_NSTAGE).total <= budget;
+    int qs = (qt < want && ld >= 512 && fits) ? SCAN_NSTAGE : 0;
+    if (const char* e = getenv("SC_SCAN_QSTREAM")) qs = (e[0] != '0' && fits) ? SCAN_NSTAGE : 0;
+    if (qs) qt = 16;
+    p->qstream = qs;
+    p->gstride = 0;
     p->qt = qt;
     p->groups = (Q + qt - 1) / qt;
     p->nwg = cus > 0 ? cus : 256;
     p->cap = cap;
     p->lists = p->nwg;  // one merged list per workgroup
-    p->lds = scan_lds_layout(ld, qt, cap, nprobe).total;
+    p->lds = scan_lds_layout(ld, qt, cap, nprobe, qs).total;
     p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t);
     return true;
+}
+
+template <int METRIC, int QS>
+static void launch_scan_exact(const ScanArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<METRIC, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((scan_exact_kernel<METRIC, QS>), grid, dim3(256), lds, s, a);
 }
 
 void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_t n, int ld, const float* Qp, const float* qnorm,
@@ -328,16 +420,15 @@ void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_
     const int64_t tiles = (n + 15) / 16;
     a.tiles_per_wg = (int)((tiles + p.nwg - 1) / p.nwg);
     a.partial = partial;
-    a.perm = perm; a.seg_base = seg_base; a.seg_rows = seg_rows; a.nprobe = nprobe; a.qmap = qmap;
-    dim3 grid((unsigned)p.nwg, (unsigned)p.groups), block(256);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    a.perm = perm; a.seg_base = seg_base; a.seg_rows = seg_rows; a.nprobe = nprobe; a.qmap = qmap; a.gstride = p.gstride;
+    dim3 grid((unsigned)p.nwg, (unsigned)p.groups);
+    if (p.qstream) {
+        if (metric == SC_METRIC_L2) launch_scan_exact<SC_METRIC_L2, 4>(a, grid, p.lds, s);
+        else if (metric == SC_METRIC_COSINE) launch_scan_exact<SC_METRIC_COSINE, 4>(a, grid, p.lds, s);
+        else launch_scan_exact<SC_METRIC_IP, 4>(a, grid, p.lds, s);
+    } else {
+        if (metric == SC_METRIC_L2) launch_scan_exact<SC_METRIC_L2, 0>(a, grid, p.lds, s);
+        else if (metric == SC_METRIC_COSINE) launch_scan_exact<SC_METRIC_COSINE, 0>(a, grid, p.lds, s);
+        else launch_scan_exact<SC_METRIC_IP, 0>(a, grid, p.lds, s);
     }
-    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_L2>, grid, block, p.lds, s, a);
-    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_COSINE>, grid, block, p.lds, s, a);
-    else hipLaunchKernelGGL(scan_exact_kernel<SC_METRIC_IP>, grid, block, p.lds, s, a);
 }

@@ -91,6 +91,30 @@ def test_listmajor_probe_equals_per_query_probe(rt, metric):
     ix.close()
 
 
+def test_listmajor_probe_with_streamed_queries(rt, monkeypatch):
+    """List-major probing on the streamed-query scan variant (the default from ~1 400 dimensions up, forced here at 96 and
+    taken by itself at 2 048): groups of up to 16 queries per list part, same bits as per-query probing."""
+    for dim, n, ncl, force in ((96, 30_000, 25, True), (2048, 12_000, 20, False)):
+        X, centers = clustered(n, dim, ncl, seed=21)
+        rng = np.random.default_rng(22)
+        ix = _native.Index(rt, dim, metric="L2", kind="IVF_FLAT", nlist=32)
+        ix.add(X)
+        ix.train(niter=4)
+        for nq, k, nprobe in ((3, 10, 2), (150, 10, 8), (64, 32, 31)):
+            Q = (centers[rng.integers(0, ncl, size=nq)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
+            ix.set_search_mode("ivf")
+            d3, r3 = ix.search(Q, k=k, nprobe=nprobe)
+            if force:
+                monkeypatch.setenv("SC_SCAN_QSTREAM", "1")
+            ix.set_search_mode("ivf_listmajor")
+            d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
+            assert ix.last_search_stats()["path"] == "ivf_listmajor"
+            if force:
+                monkeypatch.delenv("SC_SCAN_QSTREAM")
+            assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (dim, nq, k, nprobe)
+        ix.close()
+
+
 def test_recall_and_forced_probe_on_larger_set(rt):
     X, centers = clustered(300_000, 128, 500, seed=3)
     rng = np.random.default_rng(4)

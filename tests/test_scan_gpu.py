@@ -76,6 +76,39 @@ def test_k_range(rt, k):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", METRICS)
+def test_streamed_query_variant_is_bit_identical(rt, metric, monkeypatch):
+    """Long rows: the 16 queries of a pass are streamed through a shared LDS ring instead of living in LDS
+    (scan_exact.hip, QS).  Forced on at dimensions where the resident variant is the default, it must return the same bits:
+    ragged row counts (waves with unequal tile counts, workgroups without tiles), 1..16 queries, a second group."""
+    for n, dim, nq, k in ((20_001, 768, 16, 10), (20_001, 768, 5, 10), (1, 768, 3, 1), (17, 100, 16, 5), (63, 100, 1, 5),
+                          (4097, 100, 33, 10), (70_000, 256, 7, 48)):
+        X = orc.synth(n, dim, seed=31 + n)
+        Q = orc.synth(nq, dim, seed=32 + nq)
+        ix = _native.Index(rt, dim, metric=metric)
+        ix.add(X)
+        ix.set_search_mode("exact")
+        monkeypatch.setenv("SC_SCAN_QSTREAM", "0")
+        d0, r0 = ix.search(Q, k=min(k, n))
+        monkeypatch.setenv("SC_SCAN_QSTREAM", "1")
+        d1, r1 = check_exact(ix, X, Q, min(k, n), metric)
+        assert np.array_equal(r0, r1) and np.array_equal(bits(d0), bits(d1)), (n, dim, nq, k)
+        monkeypatch.delenv("SC_SCAN_QSTREAM")
+        ix.close()
+
+
+def test_streamed_query_variant_is_the_default_for_long_rows(rt):
+    """3 072-d rows leave LDS room for 6 resident queries; 16 queries then take the streamed variant in ONE pass."""
+    X = orc.synth(6_000, 3072, seed=41)
+    Q = orc.synth(16, 3072, seed=42)
+    for metric in ("L2", "COSINE"):
+        ix = _native.Index(rt, 3072, metric=metric)
+        ix.add(X)
+        ix.set_search_mode("exact")
+        check_exact(ix, X, Q, 10, metric)
+        ix.close()
+
+
 def test_bad_arguments_raise(rt):
     ix = _native.Index(rt, 64, metric="L2")
     ix.add(np.zeros((4, 64), np.float32))
