@@ -38,6 +38,7 @@ struct GemmArgs {
     int splitk;        // split-K kernels: number of K slices (grid = ntiles * splitk)
     float* partial;    // split-K kernels: [splitk][M][N] f32 partial products
     unsigned long long* trace;  // diagnostic: per-workgroup time stamps [ntiles][8] (sc_diag_gemm_trace), else nullptr
+    int nt;            // 256-tile kernel: write C with non-temporal stores (outputs far larger than L2)
 };
 
 template <int EPI>
@@ -126,7 +127,7 @@ struct ResidualTailHook {
             const int row = d * 8 + prow;
             const int cs = pos ^ ((row >> 1) & 7);
             const bf16_t* g = R + (size_t)(wm * 128 + row) * ldr + wn * 64 + cs * 8;
-            __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(dst + d * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)g, (lds_vptr)(dst + d * 1024), 16, 0, 2);
         }
     }
 };
@@ -183,7 +184,13 @@ static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u32x4 o = *reinterpret_cast<const u32x4*>(stg + (j * 8 + prow) * T_EPI_ROW + c8 * 2);
-            *reinterpret_cast<u32x4*>(cp + (size_t)(mi * 16 + j * 8) * a.ldc) = o;
+            bf16_t* dst = cp + (size_t)(mi * 16 + j * 8) * a.ldc;
+            // Large outputs are written non-temporally: a launch of the batch step writes 100-400 MB of C through 32 MB of L2
+            // and, written back normally, evicts the A row panels the next column tiles of the same panel are about to re-read
+            // (same-box A/B: QKV +3 %, out-proj +7 %, FFN1 +8 %, FFN2 +3 %, encoder 18.9k -> 19.7k chunks/s).  Inline asm because
+            // the two stores of an if/else get merged by the compiler, which drops the non-temporal hint.
+            if (a.nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+            else *reinterpret_cast<u32x4*>(dst) = o;
         }
     }
 }
@@ -238,7 +245,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
 // M, N multiples of 128; K multiple of 64; all leading dimensions multiples of 8 elements.
 bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && (M % G_BM) == 0 && (N % G_BN) == 0 && (K % G_BK) == 0; }
 
-static int g_gemm_order = 16;  // XCD remap + column-major walk inside groups of 8 row panels (profiles/r1n_gemm_tile_order.log)
+// -1 = by shape: weights that fit the L2s (the encoder's, <= 4.7 MB) walk row panel by row panel (with non-temporal C stores the
+// A panel then stays cached for all of its column tiles: encoder 19.50k -> 19.66k chunks/s in a same-box A/B); larger W walks
+// column-major inside groups of 8 row panels, which bounds the W re-reads (profiles/r1n_gemm_tile_order.log).  Both XCD-remapped.
+static int g_gemm_order = -1;
 void sc_gemm_set_order(int v) { g_gemm_order = v; }
 static unsigned long long* g_gemm_trace = nullptr;
 void sc_gemm_set_trace(unsigned long long* dev) { g_gemm_trace = dev; }
@@ -330,8 +340,9 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
     static const char* env_order = getenv("SC_GEMM_ORDER");  // A/B experiments
-    a.order = env_order ? atoi(env_order) : g_gemm_order;
+    a.order = env_order ? atoi(env_order) : g_gemm_order >= 0 ? g_gemm_order : ((size_t)N * (size_t)K * 2 <= ((size_t)8 << 20) ? 0 : 16);
     a.trace = g_gemm_trace;
+    { static const char* env_nt = getenv("SC_GEMM_NT"); a.nt = env_nt ? atoi(env_nt) : ((size_t)M * (size_t)N * 2 >= ((size_t)64 << 20)); }
     static bool attr_done = false;
     if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
         a.tiles_n = N / T_BN;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
             int64_t rr = row0 + r;
             rr = rr > tlast ? tlast : rr;
             const float* src = a.X + rr * (int64_t)ld + (iss_kc << 6) + ((pslot ^ r) << 2);
-            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(dst + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(dst + p * 1024), 16, 0, 2);
         }
         ++iss;
         if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
