@@ -204,6 +204,16 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 struct NoTailHook {
     __device__ __forceinline__ void operator()() const {}
 };
+// request K-tiles 0 and 1 of a tile (16 LDS-DMA pieces per wave)
+static __device__ __forceinline__ void gemm_tile256_prologue_issue(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W,
+                                                                    int ldw, int n0, int K, char* smem, int w, int lane) {
+    stage_tile256(A, lda, m0, 0, smem, w, lane);
+    stage_tile256(W, ldw, n0, 0, smem + T_TILE_BYTES, w, lane);
+    if (K > G_BK) {
+        stage_tile256(A, lda, m0, G_BK, smem + 2 * T_TILE_BYTES, w, lane);
+        stage_tile256(W, ldw, n0, G_BK, smem + 3 * T_TILE_BYTES, w, lane);
+    }
+}
 template <int DBG = 0, class TailHook = NoTailHook>
 static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
                                                               int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
@@ -211,16 +221,11 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
-    stage_tile256(A, lda, m0, 0, smem, w, lane);
-    stage_tile256(W, ldw, n0, 0, smem + T_TILE_BYTES, w, lane);
-    if (nk > 1) {
-        stage_tile256(A, lda, m0, G_BK, smem + 2 * T_TILE_BYTES, w, lane);
-        stage_tile256(W, ldw, n0, G_BK, smem + 3 * T_TILE_BYTES, w, lane);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 (8 pieces per wave) still in flight
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    gemm_tile256_prologue_issue(A, lda, m0, W, ldw, n0, K, smem, w, lane);
+    // tile 0 landed, tile 1 (8 pieces per wave) may still be in flight.
+    // Raw barrier: __syncthreads() would put an s_waitcnt vmcnt(0) in front of it and wait for tile 1 as well.
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     Frag256 f0, f1;
     using T = std::true_type;
     using F = std::false_type;

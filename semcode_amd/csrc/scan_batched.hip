@@ -176,56 +176,38 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 // lane queues its (rare) hits in registers so that the global atomics that allocate list slots are issued
 // back to back and their latency is paid once per tile, not once per hit.
 #define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256]} in LDS
-template <int METRIC, int DBG = 0>
-__global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 2, wn = w & 3;
-    const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    int rt = tile / a.qtiles, qt = tile - rt * a.qtiles;
-    {   // column-major walk inside groups of 8 row panels (same order as the encoder GEMMs; -12 % there)
-        const int G = 8, rtiles = a.ntiles / a.qtiles;
-        const int gsz = G * a.qtiles, g = tile / gsz, r = tile - g * gsz;
-        const int rows_here = (g * G + G <= rtiles) ? G : rtiles - g * G;
-        rt = g * G + r % rows_here;
-        qt = r / rows_here;
-    }
-    const int64_t m0 = a.row0 + (int64_t)rt * T_BM;
-    const int n0 = qt * T_BN;
+// per-tile staging of the workgroup's 256 query thresholds / norms and the tile's 256 row norms (visible to everyone after
+// the main loop's barriers)
+static __device__ __forceinline__ void coarse256_stage(const CoarseArgs& a, int64_t m0, int n0, char* smem, int tid) {
     float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
-    float* q_thr = q_tf + 256;
-    float* q_qn = q_tf + 512;
-    float* x_xn = q_tf + 768;  // |x|^2 of the tile's 256 corpus rows
     if (tid >= 256) {
         const int64_t row = m0 + (tid - 256);
-        x_xn[tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
+        q_tf[768 + tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
     }
-    if (tid < 256) {  // visible to everyone after the main loop's barriers
+    if (tid < 256) {
         const int q = n0 + tid;
         q_tf[tid] = a.thr_fast[q];  // padded to Qpad and +inf-initialised
-        q_thr[tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
-        q_qn[tid] = q < a.Q ? a.qnorm[q] : 1.0f;
+        q_tf[256 + tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
+        q_tf[512 + tid] = q < a.Q ? a.qnorm[q] : 1.0f;
     }
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_tile256_mainloop<0>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
-    asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG) {  // diagnostic: main loop only
-        float sink = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
-        if (sink == 12345.678f) a.count[0] = 1;
-        return;
-    }
-
+}
+// tile (rt, qt) of logical tile index `tile`: column-major walk inside groups of 8 row panels (as the encoder GEMMs once did)
+static __device__ __forceinline__ void coarse256_coords(const CoarseArgs& a, int tile, int64_t& m0, int& n0) {
+    const int G = 8, rtiles = a.ntiles / a.qtiles;
+    const int gsz = G * a.qtiles, g = tile / gsz, r = tile - g * gsz;
+    const int rows_here = (g * G + G <= rtiles) ? G : rtiles - g * G;
+    m0 = a.row0 + (int64_t)(g * G + r % rows_here) * T_BM;
+    n0 = (r / rows_here) * T_BN;
+}
+template <int METRIC>
+static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
+                                                          int lane) {
+    const int wm = w >> 2, wn = w & 3;
+    asm volatile("" : "+v"(lane));
+    const float* q_tf = reinterpret_cast<const float*>(smem + COARSE_QLDS);
+    const float* q_thr = q_tf + 256;
+    const float* q_qn = q_tf + 512;
+    const float* x_xn = q_tf + 768;  // |x|^2 of the tile's 256 corpus rows
     // acc[ni][mi][r] = <x[m0 + wm*128 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 tf[4];
@@ -289,6 +271,39 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     if (nh > 2 && p2 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq2) * a.cap + p2] = hk2;
     if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
+
+template <int METRIC, int DBG = 0>
+__global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int64_t m0;
+    int n0;
+    coarse256_coords(a, xcd_remap(blockIdx.x, a.ntiles), m0, n0);
+    coarse256_stage(a, m0, n0, smem, tid);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile256_mainloop<0>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+    asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG) {  // diagnostic: main loop only
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
+        if (sink == 12345.678f) a.count[0] = 1;
+        return;
+    }
+    coarse256_epilogue<METRIC>(a, acc, m0, n0, smem, w, lane);
+}
+
+// A persistent variant (one workgroup per CU walking tiles b, b + grid, ..., the tail hook of tile t requesting K-tiles 0 and 1 of
+// tile t + grid under its last 32 MFMAs) was built and measured in a same-box A/B: 64.7k -> 60.4k QPS.  Like both persistent walks
+// tried on the encoder GEMMs it loses to hardware dispatch of one workgroup per tile; DESIGN.md section 8.
 
 // ------------------------------------------------------------------ per-phase selection: keep the KPRIME best coarse keys
 // best [Q][KPRIME] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
