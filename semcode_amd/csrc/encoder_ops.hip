@@ -339,7 +339,7 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
 // 4 waves instead of 2 share a SIMD and cover each other's MFMA -> softmax -> MFMA dependency stalls)
 template <int KT, bool ALIBI, int NW = 4>
 __global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int H,
-                                                            const float* __restrict__ slopes, bf16_t* __restrict__ ctx) {
+                                                            const float* __restrict__ slopes, bf16_t* __restrict__ ctx, int blocked) {
     constexpr int S = KT * 32;
     constexpr int NQB = (KT + NW - 1) / NW;  // query blocks per wave
     constexpr int GKMAX = (NW == 8 && KT <= 8) ? 2 : 4;  // S = 512 runs one workgroup per CU anyway (LDS): registers are not its limit
@@ -351,8 +351,12 @@ __global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(c
     float* xch = reinterpret_cast<float*>(smem + 2 * S * 128) + w * 32;  // [NW waves][32] alpha / 1/l exchange
     char* ostg = smem + 2 * S * 128 + NW * 128 + w * 1024;               // per-wave [8 q][64 d] bf16 output staging
     const int head = blockIdx.x, b = blockIdx.y;
-    const int ld = 3 * H;
-    const bf16_t* base = qkv + (size_t)b * S * ld + head * 64;
+    // row-major QKV [tokens][3H] (Q | K | V, head h at column 64 h), or -- blocked -- [3 heads][tokens][64] as the QKV projection
+    // writes it (gemm_bf16.hip c_index; `blocked` = tokens padded to that GEMM's M, 0 = row-major): every operand of this (chunk, head) is then one contiguous [S][64] block
+    const int ld = blocked ? 64 : 3 * H;
+    const size_t T = (size_t)blocked, nh = (size_t)(H >> 6);  // blocked = the row count (M) of the projection that wrote the blocks
+    const bf16_t* base = blocked ? qkv + ((size_t)head * T + (size_t)b * S) * 64 : qkv + (size_t)b * S * ld + head * 64;
+    const size_t koff = blocked ? nh * T * 64 : (size_t)H, voff = 2 * koff;
     int len = lens[b];
     len = len < 1 ? 1 : (len > S ? S : len);
     len = __builtin_amdgcn_readfirstlane(len);
@@ -362,12 +366,12 @@ __global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(c
     for (int piece = w; piece < nkt * 4; piece += NW) {
         const int p = piece * 64 + lane;
         const int r = p >> 3, ck = (p & 7) ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + H + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + koff + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
     }
     for (int piece = w; piece < nkt * 4; piece += NW) {
         const int p = piece * 64 + lane;
         const int r = p >> 3, cv = (p & 7) ^ (((r >> 1) & 1) << 2);
-        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + 2 * H + cv * 8), (lds_vptr)(Vl + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)r * ld + voff + cv * 8), (lds_vptr)(Vl + piece * 1024), 16, 0, 0);
     }
     // Q fragments of all of this wave's query blocks (B operand: lane (q = lane&31, hh) holds Q[q][16 ks + 8 hh .. +7]),
     // requested now so that their latency hides behind the K/V staging
@@ -461,7 +465,7 @@ void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, cons
     else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, (const bf16_t*)in, tokens, H, g, b, eps, (bf16_t*)out);
 }
 template <int KT, bool ALIBI>
-static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, const float* slopes, void* ctx, hipStream_t s) {
+static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, const float* slopes, void* ctx, int blocked, hipStream_t s) {
     static const char* env = getenv("SC_ATTN_WAVES");  // A/B aid
     constexpr int NWD = KT >= 8 ? 8 : 4;
     const int nw = (env && KT >= 8) ? atoi(env) : NWD;
@@ -473,19 +477,19 @@ static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, cons
     }
     const dim3 grid((unsigned)(H / 64), (unsigned)B);
     if (KT >= 8 && nw == 8)
-        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, NWD>), grid, dim3(NWD * 64), (size_t)KT * 32 * 256 + NWD * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
+        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, NWD>), grid, dim3(NWD * 64), (size_t)KT * 32 * 256 + NWD * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx, blocked);
     else
-        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, 4>), grid, dim3(256), (size_t)KT * 32 * 256 + 4 * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx);
+        hipLaunchKernelGGL((attention_kernel<KT, ALIBI, 4>), grid, dim3(256), (size_t)KT * 32 * 256 + 4 * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx, blocked);
 }
 bool sc_attention_supported(int S, int H, int heads) {
     return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512);
 }
 // slopes: NULL = plain attention; else [heads] ALiBi slopes (device)
-void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s) {
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s, int blocked) {
 #define SC_ATTN_CASE(SS, KK)                                                      \
     case SS:                                                                      \
-        if (slopes) launch_attn<KK, true>(qkv, lens, B, H, slopes, ctx, s);      \
-        else launch_attn<KK, false>(qkv, lens, B, H, nullptr, ctx, s);           \
+        if (slopes) launch_attn<KK, true>(qkv, lens, B, H, slopes, ctx, blocked, s); \
+        else launch_attn<KK, false>(qkv, lens, B, H, nullptr, ctx, blocked, s);   \
         break;
     switch (S) {
         SC_ATTN_CASE(32, 1)

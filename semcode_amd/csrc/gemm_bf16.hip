@@ -39,7 +39,15 @@ struct GemmArgs {
     float* partial;    // split-K kernels: [splitk][M][N] f32 partial products
     unsigned long long* trace;  // diagnostic: per-workgroup time stamps [ntiles][8] (sc_diag_gemm_trace), else nullptr
     int nt;            // 256-tile kernel: write C with non-temporal stores (outputs far larger than L2)
+    int cblock;        // 1: C is stored as [N / 64][M][64] (64-column blocks, each contiguous over the rows) instead of [M][ldc]
 };
+
+// address of C[m][n] (n % 4 == 0 where vectors are stored): row-major, or 64-column blocks that are contiguous over the rows --
+// the QKV projection writes that, so that attention reads each head's Q / K / V as one contiguous [tokens][64] block and a wave's
+// 16 x 64 output block is 2 KiB of consecutive bytes instead of 16 segments 4.6 KB apart
+static __device__ __forceinline__ size_t c_index(const GemmArgs& a, int64_t m, int n) {
+    return a.cblock ? ((size_t)(n >> 6) * (size_t)a.M + (size_t)m) * 64 + (size_t)(n & 63) : (size_t)m * a.ldc + n;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
             u16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(v[r]);
-            *reinterpret_cast<u16x4*>(a.C + (size_t)m * a.ldc + n) = o;
+            *reinterpret_cast<u16x4*>(a.C + c_index(a, m, n)) = o;
         }
     }
 }
@@ -164,7 +172,8 @@ static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m
             for (int ni = 0; ni < 4; ++ni)
                 rr[mi][ni] = *reinterpret_cast<const u32x2*>(rlds + mi * 2048 + (((ni * 2 + (fq >> 1)) ^ swz) << 4));
     }
-    bf16_t* cp = a.C + (size_t)(m0 + wm * 128 + prow) * a.ldc + n0 + wn * 64 + c8;
+    const size_t crs = a.cblock ? 64 : (size_t)a.ldc;  // row stride of this wave's 64-column block
+    bf16_t* cp = a.C + c_index(a, m0 + wm * 128 + prow, n0 + wn * 64) + c8;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
@@ -184,7 +193,7 @@ static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const u32x4 o = *reinterpret_cast<const u32x4*>(stg + (j * 8 + prow) * T_EPI_ROW + c8 * 2);
-            bf16_t* dst = cp + (size_t)(mi * 16 + j * 8) * a.ldc;
+            bf16_t* dst = cp + (size_t)(mi * 16 + j * 8) * crs;
             // Large outputs are written non-temporally: a launch of the batch step writes 100-400 MB of C through 32 MB of L2
             // and, written back normally, evicts the A row panels the next column tiles of the same panel are about to re-read
             // (same-box A/B: QKV +3 %, out-proj +7 %, FFN1 +8 %, FFN2 +3 %, encoder 18.9k -> 19.7k chunks/s).  Inline asm because
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
             for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(rv[r]);
         }
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(a.C + c_index(a, m, n)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
 }
 
@@ -339,6 +348,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     GemmArgs a;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
+    a.cblock = ldc == SC_LDC_BLOCKED64 ? 1 : 0;
     static const char* env_order = getenv("SC_GEMM_ORDER");  // A/B experiments
     a.order = env_order ? atoi(env_order) : g_gemm_order >= 0 ? g_gemm_order : ((size_t)N * (size_t)K * 2 <= ((size_t)8 << 20) ? 0 : 16);
     a.trace = g_gemm_trace;

@@ -9,6 +9,9 @@
 #define SC_LD_ALIGN 64            // corpus row stride is a multiple of 64 floats (256 B)
 #define SC_KEY_MAX 0xFFFFFFFFFFFFFFFFull
 
+// sc_launch_gemm_bf16: ldc value that selects the 64-column-blocked output layout C[N / 64][M][64] (gemm_bf16.hip c_index);
+// sc_launch_attention reads a QKV buffer of that layout when `blocked` (= that GEMM's M) is non-zero
+#define SC_LDC_BLOCKED64 (-64)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

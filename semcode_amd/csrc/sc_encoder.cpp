@@ -27,7 +27,7 @@ void sc_launch_embed_ln(const int32_t* ids, int tokens, int S, int H, int vocab,
                         const float* temb, const float* g, const float* b, float eps, void* out, hipStream_t s);
 void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, const float* b, float eps, void* out, hipStream_t s);
 bool sc_attention_supported(int S, int H, int heads);
-void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s);
+void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s, int blocked = 0);
 void sc_launch_geglu(const void* h, int64_t tokens, int F, void* out, hipStream_t s);
 void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s);
 void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
@@ -296,11 +296,12 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
         const LayerW& w = e->layers[l];
         hipEvent_t g0, g1;
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS, e->x, H, w.wqkv, H, w.bqkv, nullptr, 0, e->qkv, 3 * H, M, 3 * H, H, s, sk, skb);
+        // QKV in 64-column blocks, i.e. [3 heads][tokens][64]: attention reads each (chunk, head) operand as one contiguous block
+        sc_launch_gemm_bf16(EPI_BIAS, e->x, H, w.wqkv, H, w.bqkv, nullptr, 0, e->qkv, SC_LDC_BLOCKED64, M, 3 * H, H, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         hipEvent_t a0, a1;
         sc_prof_begin(rt, SC_PROF_ATTN, &a0, &a1);
-        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->slopes, e->ctx, s);
+        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->slopes, e->ctx, s, M);
         sc_prof_end(rt, SC_PROF_ATTN, a0, a1);
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
         sc_launch_gemm_bf16(EPI_BIAS_RES, e->ctx, H, w.wo, H, w.bo, e->x, H, e->y, H, M, H, H, s, sk, skb);
