@@ -40,6 +40,7 @@ struct GemmArgs {
     unsigned long long* trace;  // diagnostic: per-workgroup time stamps [ntiles][8] (sc_diag_gemm_trace), else nullptr
     int nt;            // 256-tile kernel: write C with non-temporal stores (outputs far larger than L2)
     int cblock;        // 1: C is stored as [N / 64][M][64] (64-column blocks, each contiguous over the rows) instead of [M][ldc]
+    int ablock;        // 1: A is stored that way, [K / 64][M][64] (256-tile kernel only)
 };
 
 // address of C[m][n] (n % 4 == 0 where vectors are stored): row-major, or 64-column blocks that are contiguous over the rows --
@@ -228,11 +229,13 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // DBG bits: 1 no in-loop DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads (ablations, outputs meaningless);
     constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0);
+    const int lda = a.ablock ? 64 : a.lda;
+    const size_t a_kstep = a.ablock ? (size_t)a.M * 64 : (size_t)G_BK;
     if (EPI == EPI_BIAS_RES && !DBG)
-        gemm_tile256_mainloop<ML>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
-                                  ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem});
+        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
+                                  ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
     else
-        gemm_tile256_mainloop<ML>(a.A, a.lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane);
+        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane, NoTailHook{}, a_kstep);
     gemm256_stamp(a, blockIdx.x, 3);
     if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
         float sink = 0.f;
@@ -349,6 +352,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
     a.cblock = ldc == SC_LDC_BLOCKED64 ? 1 : 0;
+    a.ablock = lda == SC_LDC_BLOCKED64 ? 1 : 0;  // caller's contract: M % 256 == 0, N % 256 == 0, no split-K scratch (the 256-tile kernel)
     static const char* env_order = getenv("SC_GEMM_ORDER");  // A/B experiments
     a.order = env_order ? atoi(env_order) : g_gemm_order >= 0 ? g_gemm_order : ((size_t)N * (size_t)K * 2 <= ((size_t)8 << 20) ? 0 : 16);
     a.trace = g_gemm_trace;

@@ -196,6 +196,8 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 
 // acc[ni][mi][r] = sum_k A[m0 + wm*128 + mi*16 + (lane&15)][k] * W[n0 + wn*64 + ni*16 + 4*(lane>>4) + r][k]
 // smem: 128 KiB ([2][A tile | W tile]).  All 512 threads of the workgroup must call it.  K % 64 == 0.
+// a_kstep: elements from one K-tile of A to the next -- 64 for row-major A[M][lda]; M * 64 (with lda = 64) when A is stored in
+// 64-column blocks [K / 64][M][64], as the producing GEMM's blocked output layout writes it (gemm_bf16.hip c_index).
 // DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs, bit 2 = skip the fragment reads
 // (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).
 // tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
@@ -206,22 +208,22 @@ struct NoTailHook {
 };
 // request K-tiles 0 and 1 of a tile (16 LDS-DMA pieces per wave)
 static __device__ __forceinline__ void gemm_tile256_prologue_issue(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W,
-                                                                    int ldw, int n0, int K, char* smem, int w, int lane) {
+                                                                    int ldw, int n0, int K, char* smem, int w, int lane, size_t a_kstep = G_BK) {
     stage_tile256(A, lda, m0, 0, smem, w, lane);
     stage_tile256(W, ldw, n0, 0, smem + T_TILE_BYTES, w, lane);
     if (K > G_BK) {
-        stage_tile256(A, lda, m0, G_BK, smem + 2 * T_TILE_BYTES, w, lane);
+        stage_tile256(A + a_kstep, lda, m0, 0, smem + 2 * T_TILE_BYTES, w, lane);
         stage_tile256(W, ldw, n0, G_BK, smem + 3 * T_TILE_BYTES, w, lane);
     }
 }
 template <int DBG = 0, class TailHook = NoTailHook>
 static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
                                                               int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
-                                                              TailHook tail = TailHook{}) {
+                                                              TailHook tail = TailHook{}, size_t a_kstep = G_BK) {
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
-    gemm_tile256_prologue_issue(A, lda, m0, W, ldw, n0, K, smem, w, lane);
+    gemm_tile256_prologue_issue(A, lda, m0, W, ldw, n0, K, smem, w, lane, a_kstep);
     // tile 0 landed, tile 1 (8 pieces per wave) may still be in flight.
     // Raw barrier: __syncthreads() would put an s_waitcnt vmcnt(0) in front of it and wait for tile 1 as well.
     if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -247,7 +249,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
         __syncthreads();                                   // + every wave's reads of `cur` are complete
         if (!STAGE && !NEXT) tail();
         if (STAGE && !(DBG & 1)) {
-            stage_tile256(A, lda, m0, (kt + 2) * G_BK, cur, w, lane);
+            stage_tile256(A + (size_t)(kt + 2) * a_kstep, lda, m0, 0, cur, w, lane);
             stage_tile256(W, ldw, n0, (kt + 2) * G_BK, cur + T_TILE_BYTES, w, lane);
         }
         if (NEXT && !(DBG & 4)) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);

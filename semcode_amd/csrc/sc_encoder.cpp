@@ -291,6 +291,12 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
         sk = e->splitk;
     }
     const size_t skb = sk ? sc_encoder::SPLITK_BYTES : 0;
+    // batch steps: the FFN hidden activations travel in 64-column blocks ([F / 64][M][64]) between FFN1's epilogue and FFN2's
+    // K loop, so that a wave's 16 x 64 output block and a K-tile of an A row panel are contiguous (row-major: 128-byte pieces 6 KB
+    // apart).  Only the 256-tile kernel reads that layout: not with split-K (small M), not on the GEGLU path (element-wise kernel
+    // in between), and only when F divides into 256-column tiles.
+    static const char* env_fb = getenv("SC_FFN_BLOCKED");
+    const bool ffn_blocked = !sk && c.ffn_type != 1 && (F % 256) == 0 && (H % 256) == 0 && !(env_fb && env_fb[0] == '0');
     sc_launch_embed_ln(ids_dev, tokens, S, H, c.vocab, c.max_pos, e->wemb, e->pemb, e->temb, e->embg, e->embb, c.ln_eps, e->x, s);
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
@@ -310,14 +316,14 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
         const void* ffn_in = e->hm;
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
         if (c.ffn_type == 1) sc_launch_gemm_bf16(EPI_BIAS, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, 2 * F, M, 2 * F, H, s, sk, skb);
-        else sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, F, M, F, H, s, sk, skb);
+        else sc_launch_gemm_bf16(EPI_BIAS_GELU, e->x1, H, w.w1, H, w.b1, nullptr, 0, e->hm, ffn_blocked ? SC_LDC_BLOCKED64 : F, M, F, H, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         if (c.ffn_type == 1) {  // GEGLU: gelu(gate) * up
             sc_launch_geglu(e->hm, M, F, e->hg, s);
             ffn_in = e->hg;
         }
         sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
-        sc_launch_gemm_bf16(EPI_BIAS_RES, ffn_in, F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s, sk, skb);
+        sc_launch_gemm_bf16(EPI_BIAS_RES, ffn_in, ffn_blocked ? SC_LDC_BLOCKED64 : F, w.w2, F, w.b2, e->x1, H, e->y, H, M, H, F, s, sk, skb);
         sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
         sc_launch_layernorm(e->y, tokens, H, w.ln2g, w.ln2b, c.ln_eps, e->x, s);
     }
