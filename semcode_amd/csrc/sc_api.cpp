@@ -500,7 +500,7 @@ static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q
     sc_runtime* rt = ix->rt;
     hipStream_t s = rt->stream;
     ScanPlan plan;
-    if (!sc_scan_exact_plan(ix->ld, Q, k, rt->cus, &plan))
+    if (!sc_scan_exact_plan(ix->ld, Q, k, rt->cus, &plan, 0, 0, ix->n))
         return sc_fail(SC_ERR_UNSUPPORTED, "search: k=%d (1..1024) / dim=%d not supported by the exact scan", k, ix->dim);
     sc_status st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
     if (st) return st;

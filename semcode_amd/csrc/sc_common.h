@@ -82,7 +82,8 @@ struct ScanPlan {
     size_t partial_bytes;
 };
 // returns false when (ld, k) cannot be served by the exact kernel
-bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt = 0, int nprobe = 0);
+// n_rows > 0: size the grid for that many rows (small corpora), else one workgroup per CU
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt = 0, int nprobe = 0, int64_t n_rows = 0);
 // X [n, ld], xnorm [n]; Qp [Q, ld] zero padded, qnorm [Q]; partial: plan.partial_bytes
 // perm: stored position -> reported row (NULL = identity); seg_*: IVF probe ranges per group (NULL = all rows);
 // qmap: query slot -> row of Qp / qnorm (NULL = identity), see scan_exact.hip ScanArgs

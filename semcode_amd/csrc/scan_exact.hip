@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     }
 }
 
-bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt, int nprobe) {
+bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt, int nprobe, int64_t n_rows) {
     if (ld <= 0 || (ld % SC_LD_ALIGN) != 0 || k < 1 || k > 1024 || Q < 1) return false;
     const int cap = ((k + 16 + 63) / 64) * 64;  // >= k + 16, multiple of 64
     const unsigned budget = 160 * 1024;
@@ -395,6 +395,12 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
     p->qt = qt;
     p->groups = (Q + qt - 1) / qt;
     p->nwg = cus > 0 ? cus : 256;
+    // a small corpus (an IVF quantizer's centroids: a few hundred 16-row tiles) gets one tile per wave and no idle workgroups: every
+    // workgroup adds a k-list to the merge, and 256 lists of nprobe = 64 keys no longer fit the LDS tree merge (197 us vs 13 us)
+    if (n_rows > 0) {
+        const int64_t wgs = ((n_rows + 15) / 16 + SCAN_WAVES - 1) / SCAN_WAVES;
+        if (wgs < p->nwg) p->nwg = (int)(wgs < 1 ? 1 : wgs);
+    }
     p->cap = cap;
     p->lists = p->nwg;  // one merged list per workgroup
     p->lds = scan_lds_layout(ld, qt, cap, nprobe, qs).total;
