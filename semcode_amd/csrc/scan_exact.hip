@@ -399,7 +399,11 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
     // workgroup adds a k-list to the merge, and 256 lists of nprobe = 64 keys no longer fit the LDS tree merge (197 us vs 13 us)
     if (n_rows > 0) {
         const int64_t wgs = ((n_rows + 15) / 16 + SCAN_WAVES - 1) / SCAN_WAVES;
-        if (wgs < p->nwg) p->nwg = (int)(wgs < 1 ? 1 : wgs);
+        if (wgs < p->nwg) {
+            p->nwg = (int)(wgs < 1 ? 1 : wgs);
+            const int fit = 8192 / k;  // lists whose 2 x k keys fit the tree merge's 128 KiB
+            if (p->nwg > fit) p->nwg = fit < 1 ? 1 : fit;
+        }
     }
     p->cap = cap;
     p->lists = p->nwg;  // one merged list per workgroup
