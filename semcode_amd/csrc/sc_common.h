@@ -91,6 +91,9 @@ void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_
                           const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm,
                           const int* seg_base, const int64_t* seg_rows, int nprobe, hipStream_t s, const int32_t* qmap = nullptr);
 // partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
+// more lists than one LDS tree merge holds (2 * lists * k keys > 128 KiB) are merged in levels whose intermediate k-lists live right
+// behind the partial lists: that many extra bytes (included in ScanPlan::partial_bytes)
+size_t sc_topk_merge_scratch_bytes(int lists, int Q, int k);
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k,
                           int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
 // lists_per_query sorted k-lists per query, list j of query q = partial[src[q * lists_per_query + j] * k ...] (src < 0: none);

@@ -408,7 +408,7 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
     p->cap = cap;
     p->lists = p->nwg;  // one merged list per workgroup
     p->lds = scan_lds_layout(ld, qt, cap, nprobe, qs).total;
-    p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t);
+    p->partial_bytes = (size_t)p->groups * p->lists * qt * (size_t)k * sizeof(uint64_t) + sc_topk_merge_scratch_bytes(p->lists, p->groups * qt, k);
     return true;
 }
 
