@@ -21,12 +21,13 @@
 //     k-th best key, rare LDS append, rank-sort compaction when a candidate buffer fills;
 //   * at the end the workgroup merges its 4 waves' lists; topk_merge.hip reduces the per-workgroup lists.
 //
-// Streamed-query variant (QS = true), for rows so long that 16 resident queries no longer fit beside the ring (ld > ~1400:
+// Streamed-query variant (QS != 0), for rows so long that 16 resident queries no longer fit beside the ring (ld > ~1400:
 // 3 072-d vectors left room for 6, so a list wanted by 16 queries was streamed three times): the queries are not resident.
-// The four waves walk the k-chunks of their tiles in lock step and share a 4-deep ring of query stages (16 queries x 64
-// floats, the same XOR swizzle); wave w LDS-DMAs quarter w of every query stage from L2 (the query block is 16 x ld x 4 B and
-// stays cache resident), one raw s_barrier per stage publishes it (after the issuing wave's counted vmcnt) and frees the slot
-// the next request overwrites.  Same MFMA chain per (row, query), so results are bit-identical to the resident variant.
+// The four waves walk the k-chunks of their tiles in lock step and share a ring of three query stages, each TWO k-chunks of the
+// 16 queries (2 x 4 KiB, the same XOR swizzle); wave w LDS-DMAs quarter w of every query stage from L2 (the query block is
+// 16 x ld x 4 B and stays cache resident), and one raw s_barrier per query stage -- per two row stages -- publishes it (after the
+// issuing wave's counted vmcnt) and frees the slot the next request overwrites.  Same MFMA chain per (row, query), so results are
+// bit-identical to the resident variant.  (One k-chunk per query stage and a barrier per row stage streamed 5 % slower.)
 #include "sc_common.h"
 #include <stdlib.h>
 
@@ -84,7 +85,7 @@ __host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int ca
     unsigned o = 0;
     L.ring = o; o += SCAN_WAVES * nst * SCAN_STAGE_BYTES;
     L.norms = o; o += SCAN_WAVES * SCAN_NORM_SLOTS * SCAN_NORM_BYTES;
-    L.qs = o; o += qstream ? nst * SCAN_STAGE_BYTES : (unsigned)qt * (unsigned)(ld + SCAN_QPAD) * 4u;
+    L.qs = o; o += qstream ? 3u * 2u * SCAN_STAGE_BYTES : (unsigned)qt * (unsigned)(ld + SCAN_QPAD) * 4u;  // 3 query stages of 2 k-chunks
     L.qn = o; o += 64;
     L.thr = o; o += SCAN_WAVES * 16 * 8;
     L.cnt = o; o += SCAN_WAVES * 16 * 4;
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         ++iss;
         if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
     };
-    // QS: this wave's quarter (queries 4w .. 4w+3) of the query stage for k-chunk qiss_kc -> shared ring slot qiss & 3
+    // QS: a query stage holds TWO k-chunks of the 16 queries (8 KiB: chunk image | chunk image), three stages in the ring; this
+    // wave requests its quarter (queries 4w .. 4w+3) of both chunks.  qiss counts query stages: stage t covers row stages 2t, 2t+1.
     int qiss = 0, qiss_kc = 0, qiss_slot = 0;
     const float* qsrc = a.Qp;
     if (QS) {
@@ -242,22 +244,25 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     }
     char* qring = smem + L.qs;
     auto issue_q = [&]() {
-        __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc + (qiss_kc << 6)),
-                                         (lds_vptr)(qring + qiss_slot * SCAN_STAGE_BYTES + w * 1024), 16, 0, 0);
-        if (++qiss_slot == NST) qiss_slot = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // always two requests (the count below relies on it); past the end the chunk index just wraps
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc + (qiss_kc << 6)),
+                                             (lds_vptr)(qring + qiss_slot * (2 * SCAN_STAGE_BYTES) + h * SCAN_STAGE_BYTES + w * 1024), 16, 0, 0);
+            if (++qiss_kc == spt) qiss_kc = 0;
+        }
+        if (++qiss_slot == 3) qiss_slot = 0;
         ++qiss;
-        if (++qiss_kc == spt) qiss_kc = 0;
     };
 
 #pragma unroll 1
     for (int j = 0; j < NST - 1; ++j)
         if (iss < total_stages) {
             issue_stage();
-            if (QS) issue_q();
+            if (QS && j < 2 && 2 * qiss < total_stages) issue_q();  // queue: rows(0) q(0) rows(1) q(1) rows(2)
         }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int con_tile = 0, con_kc = 0, con_slot = 0;
+    int con_tile = 0, con_kc = 0, con_slot = 0, con_qslot = 0;
 #pragma unroll 1
     for (int si = 0; si < total_stages; ++si) {
         if (iss < total_stages) issue_stage();
@@ -269,18 +274,14 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
             else if (pend == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            // queue behind q(si), oldest first: rows(si+1) q(si+1) ... rows(si+NST-2) q(si+NST-2) rows(si+NST-1); the query piece
-            // of stage si+NST-1 is requested only after the barrier below (its slot was read in stage si-1 by all waves).
-            // pend = min(stages left, NST-1) row stages of 4 instructions, min(stages left, NST-2) query pieces
-            const int cnt = 4 * pend + (pend < NST - 2 ? pend : NST - 2);
-            switch (cnt) {
-                case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-                case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            // Steady state (six more stages exist, so every request counted here was made).  Even si = 2j needs rows(si) and
+            // q(j); younger than both: rows(si+1) q(j+1) rows(si+2) rows(si+3) = 4+2+4+4.  Odd si = 2j+1 needs rows(si); younger:
+            // q(j+1) rows(si+1) rows(si+2) q(j+2) rows(si+3) = 2+4+4+2+4.  Near the end the wait is simply complete.
+            if (si + 6 < total_stages) {
+                if (si & 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         // this wave's row fragments need only its own counted wait: in the streamed variant they are requested BEFORE the
@@ -289,14 +290,16 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
         f32x4 av[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const f32x4*>(st + (((4 * t + g) ^ r16) << 4));
-        if (QS) {
-            // raw barrier (__syncthreads() would drain vmcnt to 0 and with it the ring).  lgkmcnt(4): everything older than
-            // the four fragment reads above has returned -- in particular stage si-1's reads of the query slot that the
-            // request below overwrites (LDS returns in order; an outstanding scalar load only makes the wait stricter).
+        if (QS && !(si & 1)) {
+            // One barrier per query stage = per TWO row stages.  Raw barrier (__syncthreads() would drain vmcnt to 0 and with it
+            // the ring).  lgkmcnt(4): everything older than the four fragment reads above has returned -- in particular stage
+            // si-1's reads of the query slot that the request below overwrites (LDS returns in order; an outstanding scalar load
+            // only makes the wait stricter).  After it query stage si/2 is visible to every wave and stage si/2 - 1 is dead.
             asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
-            if (qiss < total_stages) issue_q();
+            if (2 * qiss < total_stages) issue_q();  // q(si/2 + 2) -> the slot of q(si/2 - 1)
         }
-        const char* qb = QS ? qring + con_slot * SCAN_STAGE_BYTES + r16 * 256 : qsb + (size_t)con_kc * 256u;
+        const char* qb = QS ? qring + con_qslot * (2 * SCAN_STAGE_BYTES) + (si & 1) * SCAN_STAGE_BYTES + r16 * 256 : qsb + (size_t)con_kc * 256u;
+        if (QS && (si & 1) && ++con_qslot == 3) con_qslot = 0;
         if (++con_slot == NST) con_slot = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
