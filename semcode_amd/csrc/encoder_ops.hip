@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             const int k0 = (l32 + 32 * j) * 8;
-            if (k0 < H) nxt[j] = *reinterpret_cast<const u32x4*>(in + (size_t)tok * H + k0);
+            if (k0 < H) nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + (size_t)tok * H + k0));
         }
     }
     for (int base = wave * 2; base < tokens; base += nwaves * 2) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int k0 = (l32 + 32 * j) * 8;
-                if (k0 < H) nxt[j] = *reinterpret_cast<const u32x4*>(in + (size_t)ntok * H + k0);
+                if (k0 < H) nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + (size_t)ntok * H + k0));
             }
         }
         float v[NC][8];
