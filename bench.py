@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="both", choices=["both", "embed", "scan"])
+    ap.add_argument("--workload", default="both", choices=["both", "embed", "scan"], help="both = embed + scan (+ the IVF_FLAT block at N = 1)")
     # embed
     ap.add_argument("--batch", type=int, default=256, help="chunks per step per GPU")
     ap.add_argument("--seq", type=int, default=256, help="tokens per chunk")
@@ -50,7 +50,14 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric-type", default="L2", choices=["L2", "IP", "COSINE"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="scan: also time Q in {1,16,32,256} (SURVEY 8d asks for 1, 32, 256, 1024; 16 is the exact kernel's largest single pass)")
+    ap.add_argument("--no-sweep", action="store_true", help="scan: skip the Q in {1, 16, 32, 256} sweep (SURVEY 8d: report 1, 32, 256, 1024; 16 is the exact kernel's largest single pass)")
+    ap.add_argument("--sweep", action="store_true", help="(default now; kept for old command lines)")
+    # ivf (BASELINE configs[4]): IVF_FLAT nlist 4096 / nprobe 64 over 10M x 3072, N = 1 only
+    ap.add_argument("--no-ivf", action="store_true")
+    ap.add_argument("--ivf-rows", type=int, default=10_000_000)
+    ap.add_argument("--ivf-dim", type=int, default=3072)
+    ap.add_argument("--ivf-nlist", type=int, default=4096)
+    ap.add_argument("--ivf-nprobe", type=int, default=64)
     return ap.parse_args()
 
 
@@ -151,24 +158,26 @@ def bench_embed(ctx, args) -> dict:
 
 
 def cpu_baseline_embed(args) -> dict:
-    """numpy f32 restatement (BLAS threads = host cores) on a bounded sample of the same workload."""
+    """torch-CPU f32 restatement (oracle/bert_torch.py: one sgemm over all token rows per layer matmul, threaded element-wise
+    ops, all host cores) on a bounded sample of the same workload: one full batch when the box is large, never < 32 chunks."""
     import numpy as np
 
     from oracle import bert_oracle as bo
+    from oracle import bert_torch as bt
 
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cfg = dict(bo.BERT_BASE)
     blob = bo.make_blob(cfg, 0, "bench")
-    n = 16
+    n = args.batch if cores >= 32 else 32
     rng = np.random.default_rng(1)
     ids = rng.integers(1000, 30000, size=(n, args.seq)).astype(np.int32)
     lens = np.full(n, args.seq, np.int32)
-    bo.forward(cfg, blob, ids[:2], lens[:2], dtype=np.float32)
+    bt.forward(cfg, blob, ids[:8], lens[:8], threads=cores)
     t0 = time.perf_counter()
-    bo.forward(cfg, blob, ids, lens, dtype=np.float32)
+    bt.forward(cfg, blob, ids, lens, threads=cores)
     dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return {"value": n / dt, "unit": "chunks/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of {args.batch} chunks x {args.seq} tokens, numpy f32 restatement (BLAS on all cores), {dt:.2f}s"}
+            "sample": f"{n} chunks x {args.seq} tokens in one call, torch-CPU f32 restatement of the same forward (BLAS + threaded ops on all cores), {dt:.2f}s"}
 
 
 # ------------------------------------------------------------------------------------------- scan
@@ -220,15 +229,33 @@ def bench_scan(ctx, args) -> dict:
     path, unc = st["path"], st["uncertified"]
     groups = (Q + 15) // 16  # exact path: one corpus pass per 16 queries
 
-    sweep = None
-    if args.sweep:
+    # Batch-size sweep: the scan is HBM-bound for small batches (exact f32 kernel, one corpus pass per <= 16 queries)
+    # and MFMA-bound at Q = 1024.  The exact kernel's own launches are bracketed by hipEvents like the coarse kernel's above.
+    sweep, exact_roof = None, None
+    if not args.no_sweep:
         sweep = []
         for nq in (1, 16, 32, 256):
+            if nq > Q:
+                continue
             for _ in range(2):
                 step(nq)
+            rt.set_profiling(True)
+            rt.profile_reset()
             t = timed(ctx, lambda: step(nq), args.steps)
-            sweep.append({"queries": nq, "path": ix.last_search_stats()["path"], "ms_per_batch": 1e3 * t / args.steps,
-                          "qps": nq * args.steps / t, "corpus_gbs_per_gpu": rows * dim * 4 / (t / args.steps) / 1e9})
+            k_ms, k_n = rt.profile_read(0)
+            rt.set_profiling(False)
+            p = ix.last_search_stats()["path"]
+            sweep.append({"queries": nq, "path": p, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps * world / t,
+                          "scan_kernel_ms_per_batch": k_ms / args.steps, "corpus_gbs_per_gpu": rows * dim * 4 / (t / args.steps) / 1e9})
+            if p == "exact" and k_n and nq in (1, 16):
+                ach = rows * dim * 4 / (k_ms / k_n * 1e-3) / 1e9
+                cand = {"bound": "hbm", "kernel": "scan_exact_kernel", "queries": nq, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": rows * dim * 4, "avg_launch_ms": k_ms / k_n, "launches": k_n,
+                        "end_to_end_gbs": rows * dim * 4 / (t / args.steps) / 1e9,
+                        "traffic": ((pmc_traffic() or {}).get("scan_exact_kernel", {}).get("fetch_bytes_x2_per_launch") or None) if (rows, dim) == (10_000_000, 768) else None,
+                        "traffic_note": f"HBM-side bytes per launch, {(pmc_traffic() or {}).get('_file')} (one corpus pass; f32 shard = rows*dim*4)"}
+                if exact_roof is None or nq == 1:
+                    exact_roof = cand
     ix.close()
 
     stats = None
@@ -269,6 +296,8 @@ def bench_scan(ctx, args) -> dict:
     }
     if sweep:
         res["sweep"] = sweep
+    if exact_roof:
+        res["exact_scan_roofline"] = exact_roof  # the HBM-bound regime of the same path (Q <= 16): north_star's ">= 60 % of HBM roofline"
     return res
 
 
@@ -286,19 +315,113 @@ def coarse_traffic(rows: int, Q: int):
 
 
 def cpu_baseline_scan(args) -> dict:
-    """The oracle (scalar fmaf-chain C port, OpenMP) on a bounded sample: 200k of the rows, all queries."""
+    """CPU twins of the scan on a bounded sample (all host cores, count stated): the value is the sgemm formulation a CPU
+    implementation would use (|x|^2 + |q|^2 - 2 X Q^T by BLAS + partial sort: oracle.sc_oracle.search_sgemm); the canonical
+    fmaf-chain C port that defines the bit-exact arithmetic (the parity oracle, OpenMP over rows) is timed beside it."""
     from oracle import sc_oracle as orc
 
-    rows, nq = 200_000, args.queries
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rows, nq = 1_000_000, args.queries
     X = orc.synth(rows, args.dim, seed=0)
     Q = orc.synth(nq, args.dim, seed=1)
+    orc.search_sgemm(X[:20_000], Q[:64], args.k, args.metric_type, threads=cores)
+    t0 = time.perf_counter()
+    sd, sr = orc.search_sgemm(X, Q, args.k, args.metric_type, threads=cores)
+    dt = time.perf_counter() - t0
+    crow = 200_000
     orc.search(X[:2000], Q[:4], args.k, args.metric_type)  # warm the thread pool
     t0 = time.perf_counter()
-    orc.search(X, Q, args.k, args.metric_type)
-    dt = time.perf_counter() - t0
-    scaled = dt * (args.rows / rows)  # exhaustive scan: linear in rows
-    return {"value": nq / scaled, "unit": "queries/s", "cores": orc.threads(), "kind": "port",
-            "sample": f"{rows} of {args.rows} rows x all {nq} queries in {dt:.2f}s, scaled linearly in rows"}
+    cd, cr = orc.search(X[:crow], Q, args.k, args.metric_type)
+    dtc = time.perf_counter() - t0
+    return {"value": nq / (dt * (args.rows / rows)), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"sgemm + partial sort (torch CPU, f32) over {rows} of {args.rows} rows x all {nq} queries in {dt:.2f}s, scaled linearly in rows (exhaustive scan)",
+            "canonical_port": {"value": nq / (dtc * (args.rows / crow)), "unit": "queries/s", "cores": orc.threads(),
+                               "sample": f"scalar fmaf-chain C port (the parity oracle), {crow} rows x {nq} queries in {dtc:.2f}s, scaled linearly"}}
+
+
+# -------------------------------------------------------------------------------------------- ivf
+
+def bench_ivf(ctx, args) -> dict:
+    """BASELINE configs[4]: IVF_FLAT nlist 4096 / nprobe 64 over 10M x 3072, batch-1024 queries, k 10, L2 (index parameters of
+    reference milvus_store.py:76-83,141-147 at benchmark scale).  Corpus: clustered synthetic rows generated on device (one
+    true cluster per list); queries: rows of the same distribution that are not in the corpus.  Ground truth for recall@10 =
+    the exhaustive (certified-exact) search of the same index.  One step = one list-major probe of the whole batch."""
+    import numpy as np
+    import torch
+
+    from semcode_amd import _native
+
+    rows, dim, nlist, nprobe, Q, k = args.ivf_rows, args.ivf_dim, args.ivf_nlist, args.ivf_nprobe, args.queries, args.k
+    rt, dev = ctx.rt, ctx.dev
+    ix = _native.Index(rt, dim, metric="L2", kind="IVF_FLAT", nlist=nlist)
+    ix.fill_synthetic_clustered(rows, seed=0, nclusters=nlist, spread=0.5)
+    qsrc = _native.Index(rt, dim, metric="L2")
+    qsrc.fill_synthetic_clustered(Q, seed=0, nclusters=nlist, spread=0.5, first_row=rows + 12345)
+    qh = qsrc.get_rows(0, Q)
+    qsrc.close()
+    q = torch.from_numpy(qh).to(dev)
+    out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    out_r = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    ix.search_dev(q.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nlist)  # untrained: exhaustive
+    rt.synchronize()
+    t0 = time.perf_counter()
+    ix.search_dev(q.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nlist)
+    rt.synchronize()
+    t_bf = time.perf_counter() - t0
+    bf_stats = ix.last_search_stats()
+    truth = out_r.cpu().numpy().copy()
+    ix.release_scratch()  # the 61 GB bf16 shadow makes room for the second corpus copy of the build
+    t0 = time.perf_counter()
+    ix.train(niter=10)
+    rt.synchronize()
+    t_train = time.perf_counter() - t0
+    sizes = ix.ivf_info()["list_sizes"]
+    ix.set_search_mode("ivf_listmajor")
+
+    def step():
+        ix.search_dev(q.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nprobe)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    rt.set_profiling(True)
+    rt.profile_reset()
+    dt = timed(ctx, step, args.steps)
+    k_ms, k_n = rt.profile_read(0)
+    rt.set_profiling(False)
+    got = out_r.cpu().numpy()
+    recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(got.tolist(), truth.tolist())]))
+    pst = ix.last_probe_stats()
+    ix.set_search_mode("auto")
+    step()
+    rt.synchronize()
+    t0 = time.perf_counter()
+    step()
+    rt.synchronize()
+    t_auto = time.perf_counter() - t0
+    auto_path = ix.last_search_stats()["path"]
+    ix.set_search_mode("ivf")
+    ix.search_dev(q.data_ptr(), 1, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nprobe)
+    rt.synchronize()
+    t0 = time.perf_counter()
+    ix.search_dev(q.data_ptr(), 1, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nprobe)
+    rt.synchronize()
+    t_one = time.perf_counter() - t0
+    ix.close()
+    step_s = dt / args.steps
+    ld = (dim + 63) // 64 * 64
+    streamed, unique = pst["streamed_rows"] * ld * 4, pst["unique_rows"] * ld * 4
+    kern_s = (k_ms / args.steps) * 1e-3 if k_n else None
+    return {"value": Q / step_s, "unit": "queries/s", "ms_per_step": 1e3 * step_s, "recall_at_10": recall, "path": "ivf_listmajor",
+            "workload": f"IVF_FLAT nlist={nlist} nprobe={nprobe}, {rows} x {dim} f32 rows (clustered synthetic, device generated), batch-{Q} queries, L2 top-{k}",
+            "train_s": t_train, "list_size_min_median_max": [int(sizes.min()), int(np.median(sizes)), int(sizes.max())],
+            "roofline": {"bound": "hbm", "kernel": "scan_exact_kernel (list-major segment mode)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved": unique / kern_s / 1e9 if kern_s else None, "frac": unique / kern_s / 1e9 / HBM_PEAK_GBS if kern_s else None,
+                         "algorithmic_bytes_per_step": unique, "streamed_bytes_per_step": streamed, "groups": pst["groups"],
+                         "kernel_ms_per_step": k_ms / args.steps if k_n else None,
+                         "note": "algorithmic = bytes of the DISTINCT probed lists (SURVEY 8d config 5); streamed = what the kernel reads "
+                                 "(a list wanted by more than 16 queries is streamed once per group of 16; repeats are mostly served by L2/MALL)"},
+            "exhaustive": {"ms_per_batch": 1e3 * t_bf, "qps": Q / t_bf, "path": bf_stats["path"], "uncertified": bf_stats["uncertified"]},
+            "auto_planner": {"path": auto_path, "ms_per_batch": 1e3 * t_auto}, "single_query_ms": 1e3 * t_one}
 
 
 # ------------------------------------------------------------------------------------------- main
@@ -334,12 +457,14 @@ def main() -> None:
     ctx.rt = _native.Runtime(device=local, stream=stream.cuda_stream)
     info = ctx.rt.device_info()
 
-    embed = scan = None
+    embed = scan = ivf = None
     with torch.cuda.stream(stream):
         if args.workload in ("both", "embed"):
             embed = bench_embed(ctx, args)
         if args.workload in ("both", "scan"):
             scan = bench_scan(ctx, args)
+        if args.workload == "both" and ctx.world == 1 and not args.no_ivf:
+            ivf = bench_ivf(ctx, args)
 
     line = {
         "metric": "chunks/sec embed (256-tok) + top-k QPS over 10M x 768",
@@ -353,6 +478,8 @@ def main() -> None:
                      "roofline": embed["roofline"]})
         if scan:
             line["topk"] = scan
+        if ivf:
+            line["ivf"] = ivf
     else:
         line.update({"value": scan["value"], "unit": "queries/s", "ms_per_step": scan["ms_per_step"], "dtype": "f32",
                      "config": {"workload": scan["workload"], "sharding": f"row-range x{ctx.world}", "device": info["name"]},

@@ -22,7 +22,8 @@
  *   - host pointers are contiguous, little-endian, row-major; the caller owns every buffer
  *     it passes, the library owns only handle-internal device memory;
  *   - "_dev" variants take DEVICE pointers (e.g. torch tensor data_ptr()) and enqueue on the
- *     runtime's stream without synchronising; host variants synchronise before returning;
+ *     runtime's stream; where one of them has to wait for the stream (a flag read back, a host
+ *     table that must outlive a kernel) its comment says so; host variants always synchronise;
  *   - row ids are int64 row numbers (shard base + local row); string primary keys and
  *     metadata stay in Python (milvus_store.py:110-130 column lists);
  *   - a handle may be used from several threads (FastAPI threadpool, api/main.py:202):
@@ -74,6 +75,8 @@ sc_status sc_last_error(char* buf, size_t n);
 
 /* Replaces pymilvus connections.connect(...) (milvus_store.py:42-47): binds a device. */
 sc_status sc_runtime_create(const sc_runtime_cfg* cfg, sc_runtime** out);
+/* Drops the creator's reference.  Indexes, encoders and communicators created on the runtime hold references of their own,
+ * so they stay usable and may be destroyed afterwards, in any order; the stream is released with the last of them. */
 sc_status sc_runtime_destroy(sc_runtime* rt);
 /* Re-point the runtime at another hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
 sc_status sc_runtime_set_stream(sc_runtime* rt, void* stream);
@@ -202,8 +205,9 @@ sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const int64_t* row
  * (append; new rows must be numbered old_rows, old_rows+1, ... in the order they appear).  Row numbers must be
  * distinct.  One Collection.upsert batch (milvus_store.py:119-130) without the add/overwrite split. */
 sc_status sc_index_put_rows(sc_index* ix, const float* vecs, const int64_t* rows, int64_t n);
-/* Same with vecs a DEVICE pointer ([n,dim] f32, tight); rows stays a host pointer.  Asynchronous on the runtime's
- * stream: the embed -> store hand-over without a trip through host memory. */
+/* Same with vecs a DEVICE pointer ([n,dim] f32, tight); rows stays a host pointer.  The copy of the vectors is enqueued on
+ * the runtime's stream (the embed -> store hand-over without a trip through host memory); the call itself
+ * waits for the stream before returning, because `rows` is the caller's pageable memory. */
 sc_status sc_index_put_rows_dev(sc_index* ix, const float* vecs_dev, const int64_t* rows, int64_t n);
 /* Copy rows [first, first+n) back to the host as [n,dim] (persistence, tests). */
 sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, float* out);
@@ -222,16 +226,24 @@ sc_status sc_index_release_scratch(sc_index* ix);
  * nprobe is ignored by FLAT indexes.  Distances: L2 = squared L2, IP = dot, COSINE = cosine. */
 sc_status sc_index_search(sc_index* ix, const float* q, int32_t Q, int32_t k, int32_t nprobe,
                           float* out_dist, int64_t* out_rows);
-/* Same with DEVICE pointers (q row stride = dim); asynchronous on the runtime's stream. */
+/* Same with DEVICE pointers (q row stride = dim): enqueued on the runtime's stream.  The exact scan (<= 16 queries, no IVF
+ * probe) returns without waiting.  The batched path (bf16 coarse + f32 re-rank) reads the per-query certificate flags back and
+ * so synchronises the stream once per call, and list-major IVF probing synchronises twice (probe ids to the host planner, plan
+ * tables alive until the scan has run); the per-index mutex is held meanwhile.  Results are complete once the stream has
+ * passed the call in either case. */
 sc_status sc_index_search_dev(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe,
                               float* out_dist_dev, int64_t* out_rows_dev);
 
 /* Replaces Collection.create_index(IVF_FLAT, nlist) + load() (milvus_store.py:76-84) for an index created with
  * SC_INDEX_IVF_FLAT: deterministic k-means (niter Lloyd iterations on <= 256*nlist sampled rows), assignment of
- * every row to its nearest centroid, list-major re-ordering of the corpus in HBM.  Until it is called (and again
- * after any add / overwrite, which drop the lists) an IVF_FLAT index answers with the exhaustive scan.  After it,
- * searches with Q * nprobe < nlist probe only the nprobe nearest lists (approximate, like the reference);
- * larger batches keep using the exhaustive paths, whose results are a superset in quality. */
+ * every row to its nearest centroid, list-major re-ordering of the corpus in HBM.  Until it is called an IVF_FLAT index
+ * answers with the exhaustive scan.  After it, searches with Q * nprobe < nlist probe only the nprobe nearest lists
+ * (approximate, like the reference); larger batches probe list-major or, where that is estimated to be cheaper, keep using the
+ * exhaustive paths, whose results are a superset in quality.
+ * Upserts into a trained index (sc_index_add / _overwrite / _put_rows*) KEEP the lists -- Collection.upsert into an indexed
+ * collection does not retrain either (milvus_store.py:128): the next search first assigns the new and the replaced rows to the
+ * existing centroids and re-orders the corpus once (one pass over it, no k-means; the result is exactly what
+ * sc_index_assign_lists builds from scratch for these centroids).  k-means runs again only when this function is called. */
 sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed);
 /* Persistence of a trained index (the `ivf.*` files of the on-disk collection): the list of every row in insertion order
  * (out [rows] int32), and the inverse -- install centroids [nlist, dim] + that list without running k-means. */
@@ -255,6 +267,11 @@ sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode);
 /* After a search: which path ran (1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major) and how many queries the batched path had to
  * re-run through the exact scan because their certificate failed. */
 sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified);
+
+/* After an IVF probe search: rows of the DISTINCT lists the batch probed (`unique_rows`: the algorithmic bytes of SURVEY.md 8d
+ * config 5 = unique_rows * ld * 4), rows the scan kernel streamed (`streamed_rows`: list-major probing streams a list once per
+ * group of <= 16 queries that want it; per-query probing once per query) and the number of (list part, query group) work items. */
+sc_status sc_index_last_probe_stats(sc_index* ix, int64_t* unique_rows, int64_t* streamed_rows, int32_t* groups);
 
 /* Multi-GPU final step (one process per GPU): merge `lists` per-shard results
  * dist [lists,Q,k] / rows [lists,Q,k] (as produced by sc_index_search* on each shard and

@@ -68,7 +68,7 @@ def lib() -> C.CDLL:
         h.sc_oracle_set_threads.argtypes = [C.c_int32]
         # never more OpenMP threads than CPUs this process may run on (cgroup-limited GPU boxes)
         try:
-            h.sc_oracle_set_threads(max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 32)))
+            h.sc_oracle_set_threads(max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1)))
         except AttributeError:  # pragma: no cover
             pass
         _lib = h
@@ -126,6 +126,17 @@ def synth_clustered(rows: int, dim: int, seed: int, nclusters: int, spread: floa
     return (np.float64(np.float32(spread)) * noise.astype(np.float64) + centres.astype(np.float64)).astype(np.float32)
 
 
+def synth_clustered_rows(rows_idx, dim: int, seed: int, nclusters: int, spread: float) -> np.ndarray:
+    """Arbitrary (global) rows of the clustered corpus: the same rule as synth_clustered, random access."""
+    rows_idx = np.ascontiguousarray(rows_idx, dtype=np.int64)
+    cseed = seed ^ 0xC1057E25
+    ckey = _mix64((cseed + 0x9E3779B97F4A7C15) & M64)
+    cl = np.array([_mix64(ckey ^ ((int(r) * 0x9E3779B97F4A7C15) & M64)) % nclusters for r in rows_idx], dtype=np.int64)
+    noise = synth_rows(rows_idx, dim, seed)
+    centres = synth_rows(cl, dim, cseed)
+    return (np.float64(np.float32(spread)) * noise.astype(np.float64) + centres.astype(np.float64)).astype(np.float32)
+
+
 def sqnorm(x: np.ndarray) -> float:
     x = np.ascontiguousarray(x, dtype=np.float32)
     return float(lib().sc_oracle_sqnorm(x.ctypes.data_as(C.c_void_p), x.shape[0]))
@@ -165,6 +176,34 @@ def search_rows(X: np.ndarray, q: np.ndarray, rows, k: int, metric: str = "L2"):
 
 def threads() -> int:
     return int(lib().sc_oracle_threads())
+
+
+def search_sgemm(X: np.ndarray, Q: np.ndarray, k: int, metric: str = "L2", threads: int | None = None, block: int = 131072):
+    """The formulation a CPU implementation would use (bench.py's cpu_baseline): scores by BLAS sgemm over blocks of rows
+    (L2 = |x|^2 + |q|^2 - 2 X Q^T), a partial sort per block, a final (score, row) sort of the block winners.  f32 arithmetic
+    in BLAS order, so distances agree with search() to rounding only -- a timing twin, not the parity oracle."""
+    import torch
+
+    if threads:
+        torch.set_num_threads(int(threads))
+    Xt, Qt = torch.from_numpy(np.ascontiguousarray(X, np.float32)), torch.from_numpy(np.ascontiguousarray(Q, np.float32))
+    qn = (Qt * Qt).sum(1)
+    best_s, best_r = [], []
+    with torch.no_grad():
+        for r0 in range(0, Xt.shape[0], block):
+            xb = Xt[r0:r0 + block]
+            s = Qt @ xb.T
+            if metric == "L2":
+                s = (xb * xb).sum(1)[None, :] + qn[:, None] - 2.0 * s
+            elif metric == "COSINE":
+                s = s / (torch.sqrt((xb * xb).sum(1))[None, :] * torch.sqrt(qn)[:, None])
+            v, i = torch.topk(s, min(k, xb.shape[0]), dim=1, largest=(metric != "L2"))
+            best_s.append(v)
+            best_r.append(i + r0)
+        v, r = torch.cat(best_s, 1).numpy(), torch.cat(best_r, 1).numpy()
+    key = v if metric == "L2" else -v
+    order = np.lexsort((r, key), axis=1)[:, :k]
+    return np.take_along_axis(v, order, 1).astype(np.float32), np.take_along_axis(r, order, 1).astype(np.int64)
 
 
 # ---------------------------------------------------------------- independent float64 reference

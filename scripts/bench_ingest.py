@@ -57,7 +57,7 @@ def main() -> None:
         toks = rng.choice(len(plain), size=215)
         body = " ".join(plain[t] if j % 9 else plain[t] + "(x):" for j, t in enumerate(toks))  # ~254 word pieces with the punctuation
         chunks.append(Chunk(body, root / "src" / f"m{i}.py", "python", 1, 40))
-    emb = MI355XEmbeddings(vocab=tmp / "vocab.txt", max_tokens=256)
+    emb = MI355XEmbeddings(vocab=tmp / "vocab.txt", max_tokens=256, allow_synthetic=True)  # random-init benchmark weights
     ids, lens = emb.tokenize([c.content for c in chunks[:256]])
     print(f"chunks {n}, tokens per chunk: mean {lens.mean():.0f} max {lens.max()} (bucket {ids.shape[1]})", flush=True)
     t0 = time.perf_counter()

@@ -29,7 +29,7 @@ def timed(fn, reps=30):
 def main():
     tmp = Path(tempfile.mkdtemp(dir="gpurun_out"))
     plain = make_vocab(tmp / "vocab.txt")
-    emb = MI355XEmbeddings(vocab=tmp / "vocab.txt", max_tokens=256)
+    emb = MI355XEmbeddings(vocab=tmp / "vocab.txt", max_tokens=256, allow_synthetic=True)  # random-init benchmark weights
     rng = np.random.default_rng(0)
     for words in (12, 50, 200):
         text = " ".join(plain[i] for i in rng.choice(len(plain), size=words))

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sc_index_ivf_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sc_topk_merge_host": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -349,8 +350,14 @@ class Index:
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
         return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
 
+    def last_probe_stats(self) -> dict:
+        """After a list-major IVF probe: rows of the distinct probed lists, rows streamed, work items (sc_index_last_probe_stats)."""
+        u, st, g = C.c_int64(), C.c_int64(), C.c_int32()
+        _check(lib().sc_index_last_probe_stats(self.handle, C.byref(u), C.byref(st), C.byref(g)))
+        return {"unique_rows": u.value, "streamed_rows": st.value, "groups": g.value}
+
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
-        """Device-pointer variant (asynchronous on the runtime's stream)."""
+        """Device-pointer variant (enqueued on the runtime's stream; see sc_index_search_dev for where it synchronises)."""
         _check(lib().sc_index_search_dev(self.handle, C.c_void_p(q_ptr), int(Q), int(k), int(nprobe), C.c_void_p(dist_ptr), C.c_void_p(rows_ptr)))
 
 

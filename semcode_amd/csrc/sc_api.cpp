@@ -83,13 +83,22 @@ static void prof_clear(sc_runtime* rt) {
     }
 }
 
-extern "C" sc_status sc_runtime_destroy(sc_runtime* rt) {
-    if (!rt) return SC_OK;
+void sc_runtime_retain(sc_runtime* rt) { rt->refs.fetch_add(1, std::memory_order_relaxed); }
+
+void sc_runtime_release(sc_runtime* rt) {
+    if (rt->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     hipSetDevice(rt->device);
     hipStreamSynchronize(rt->stream);
     prof_clear(rt);
     if (rt->own_stream) hipStreamDestroy(rt->stream);
     delete rt;
+}
+
+// Drops the creator's reference.  Indexes / encoders still alive keep the runtime (device binding + stream) alive until
+// they are destroyed themselves: their destroy paths synchronise on rt->stream, which must not be a freed handle.
+extern "C" sc_status sc_runtime_destroy(sc_runtime* rt) {
+    if (!rt) return SC_OK;
+    sc_runtime_release(rt);
     return SC_OK;
 }
 
@@ -194,6 +203,7 @@ extern "C" sc_status sc_index_create(sc_runtime* rt, int32_t dim, sc_metric metr
     sc_index* ix = new (std::nothrow) sc_index();
     if (!ix) return sc_fail(SC_ERR_NOMEM, "out of host memory");
     ix->rt = rt;
+    sc_runtime_retain(rt);
     ix->dim = dim;
     ix->ld = round_up(dim, SC_LD_ALIGN);
     ix->metric = metric;
@@ -220,11 +230,12 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->bscratch);
     hipFree(ix->fb);
     hipFree(ix->perm);
-    hipFree(ix->inv);
     hipFree(ix->list_off);
     hipFree(ix->ivf_scratch);
     if (ix->quant) sc_index_destroy(ix->quant);
+    sc_runtime* rt = ix->rt;
     delete ix;
+    sc_runtime_release(rt);
     return SC_OK;
 }
 
@@ -292,9 +303,8 @@ extern "C" sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n) {
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
     if (ix->n + n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "sc_index_add: more than 2^32 rows per shard");
-    sc_status st = sc_ivf_untrain_locked(ix);  // new rows belong to no list: back to insertion order until retrained
-    if (st) return st;
-    st = ensure_rows(ix, ix->n + n, false);
+    // a trained index keeps its lists: the new rows wait behind them (position == row id) for sc_ivf_refresh_locked
+    sc_status st = ensure_rows(ix, ix->n + n, false);
     if (st) return st;
     const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4));
     hipStream_t s = ix->rt->stream;
@@ -308,7 +318,7 @@ extern "C" sc_status sc_index_add(sc_index* ix, const float* vecs, int64_t n) {
         SC_HIP(hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
     }
     ix->n += n;
-    ix->trained = false;
+    if (!ix->perm) ix->trained = false;
     return SC_OK;  // rows [shadow_rows, n) get their bf16 shadow lazily
 }
 
@@ -319,27 +329,7 @@ extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const i
     SC_HIP(hipSetDevice(ix->rt->device));
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= ix->n) return sc_fail(SC_ERR_INVALID, "sc_index_overwrite: row %lld out of range [0,%lld)", (long long)rows[i], (long long)ix->n);
-    {
-        sc_status ust = sc_ivf_untrain_locked(ix);
-        if (ust) return ust;
-    }
-    const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4 + 8));
-    hipStream_t s = ix->rt->stream;
-    for (int64_t off = 0; off < n; off += chunk) {
-        const int64_t m = std::min(chunk, n - off);
-        const size_t vbytes = ((size_t)m * ix->dim * 4 + 15) & ~(size_t)15;
-        sc_status st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, vbytes + (size_t)m * 8);
-        if (st) return st;
-        int64_t* drows = (int64_t*)((char*)ix->stage + vbytes);
-        SC_HIP(hipMemcpyAsync(ix->stage, vecs + off * ix->dim, (size_t)m * ix->dim * 4, hipMemcpyHostToDevice, s));
-        SC_HIP(hipMemcpyAsync(drows, rows + off, (size_t)m * 8, hipMemcpyHostToDevice, s));
-        sc_launch_ingest_rows((const float*)ix->stage, drows, 0, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
-        SC_HIP(hipGetLastError());
-        SC_HIP(hipStreamSynchronize(s));
-    }
-    ix->trained = false;
-    ix->shadow_rows = 0;  // overwritten rows invalidate the bf16 shadow
-    return SC_OK;
+    return sc_index_put_rows_locked(ix, vecs, false, rows, n, "sc_index_overwrite");
 }
 
 // rows[i] <- vecs[i], appends allowed (see include/semcode_hip.h sc_index_put_rows).  vecs: host or device [n, dim].
@@ -358,17 +348,31 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
         std::sort(sorted.begin(), sorted.end());
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return sc_fail(SC_ERR_INVALID, "%s: row numbers must be distinct", who);
     }
-    sc_status st = sc_ivf_untrain_locked(ix);
-    if (st) return st;
-    st = ensure_rows(ix, next, false);
+    sc_status st = ensure_rows(ix, next, false);
     if (st) return st;
     hipStream_t s = ix->rt->stream;
+    // Trained layout: a row of the lists lives at inv_h[row] (replaced in place, re-assigned to its list at the next search);
+    // appended rows go behind the lists at position == row id.  The translated positions are a temporary: synchronise
+    // before it goes out of scope (upserts into a trained index are not asynchronous).
+    std::vector<int64_t> pos;
+    if (ix->perm) {
+        pos.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            pos[(size_t)i] = sc_ivf_pos(ix, rows[i]);
+            if (rows[i] < ix->ivf_rows) ix->dirty_rows.push_back(rows[i]);
+        }
+        min_old = INT64_MAX;  // the shadow is indexed by stored position
+        for (int64_t i = 0; i < n; ++i)
+            if (rows[i] < ix->n) min_old = std::min(min_old, pos[(size_t)i]);
+        rows = pos.data();
+    }
     if (vecs_on_device) {
         st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)n * 8);
         if (st) return st;
         SC_HIP(hipMemcpyAsync(ix->stage, rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
         sc_launch_ingest_rows(vecs, (const int64_t*)ix->stage, 0, n, ix->dim, ix->X, ix->ld, ix->xnorm, s);
         SC_HIP(hipGetLastError());
+        if (ix->perm) SC_HIP(hipStreamSynchronize(s));
     } else {
         const int64_t chunk = std::max<int64_t>(1, STAGE_ROWS_BYTES / ((int64_t)ix->dim * 4 + 8));
         for (int64_t off = 0; off < n; off += chunk) {
@@ -385,7 +389,7 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
         }
     }
     ix->n = next;
-    ix->trained = false;
+    if (!ix->perm) ix->trained = false;
     if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the bf16 shadow; appended rows get theirs lazily
     return SC_OK;
 }
@@ -421,9 +425,9 @@ extern "C" sc_status sc_index_get_rows(sc_index* ix, int64_t first, int64_t n, f
         const int64_t m = std::min(chunk, n - off);
         sc_status st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, (size_t)m * ix->dim * 4);
         if (st) return st;
-        if (ix->trained) {  // list-major storage: fetch row ids first+off .. through the inverse permutation
+        if (ix->perm) {  // list-major storage: fetch row ids first+off .. through the inverse permutation
             std::vector<int64_t> pos((size_t)m);
-            for (int64_t i = 0; i < m; ++i) pos[(size_t)i] = ix->inv_h[(size_t)(first + off + i)];
+            for (int64_t i = 0; i < m; ++i) pos[(size_t)i] = sc_ivf_pos(ix, first + off + i);
             st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, (size_t)m * 8);
             if (st) return st;
             SC_HIP(hipMemcpyAsync(ix->ivf_scratch, pos.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
@@ -444,10 +448,7 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
     if (n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
-    {
-        sc_status ust = sc_ivf_untrain_locked(ix);
-        if (ust) return ust;
-    }
+    sc_ivf_drop_lists_locked(ix);
     ix->n = 0;  // nothing to preserve
     sc_status st = ensure_rows(ix, n, true);
     if (st) return st;
@@ -465,10 +466,9 @@ extern "C" sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, 
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
     if (n > 0xFFFFFFF0ll) return sc_fail(SC_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
-    sc_status st = sc_ivf_untrain_locked(ix);
-    if (st) return st;
+    sc_ivf_drop_lists_locked(ix);
     ix->n = 0;
-    st = ensure_rows(ix, n, true);
+    sc_status st = ensure_rows(ix, n, true);
     if (st) return st;
     sc_launch_synth_clustered(ix->X, n, ix->dim, ix->ld, seed, first_row, nclusters, spread, ix->xnorm, ix->rt->stream);
     SC_HIP(hipGetLastError());
@@ -661,6 +661,13 @@ sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int
 static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
                                    int64_t* out_rows) {
     ix->last_probed_lists = 0;
+    ix->last_unique_rows = ix->last_streamed_rows = 0;
+    ix->last_groups = 0;
+    {   // rows upserted since the IVF lists were built join their lists first (no k-means): the reported ids of a
+        // list-major corpus go through ix->perm, which must cover every stored row
+        sc_status rst = sc_ivf_refresh_locked(ix);
+        if (rst) return rst;
+    }
     if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
         return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
@@ -683,6 +690,15 @@ extern "C" sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int
     std::lock_guard<std::mutex> g(ix->mu);
     if (path) *path = ix->last_path;
     if (uncertified) *uncertified = ix->last_uncertified;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_probe_stats(sc_index* ix, int64_t* unique_rows, int64_t* streamed_rows, int32_t* groups) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (unique_rows) *unique_rows = ix->last_unique_rows;
+    if (streamed_rows) *streamed_rows = ix->last_streamed_rows;
+    if (groups) *groups = ix->last_groups;
     return SC_OK;
 }
 

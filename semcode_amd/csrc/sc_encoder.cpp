@@ -123,6 +123,7 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
     sc_encoder* e = new (std::nothrow) sc_encoder();
     if (!e) return sc_fail(SC_ERR_NOMEM, "out of host memory");
     e->rt = rt;
+    sc_runtime_retain(rt);
     e->cfg = *cfg;
     const int64_t H = cfg->hidden, F = cfg->ffn, L = cfg->layers, F1 = cfg->ffn_type == 1 ? 2 * F : F;
     const bool alibi = cfg->pos_type == 1;
@@ -132,12 +133,14 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
     hipError_t he = hipMalloc((void**)&blob, (size_t)nfl * 4);
     if (he != hipSuccess) {
         delete e;
+        sc_runtime_release(rt);
         return sc_fail(SC_ERR_NOMEM, "hipMalloc weight staging (%lld B) failed: %s", (long long)nfl * 4, hipGetErrorString(he));
     }
     auto fail = [&](sc_status code) {
         hipFree(blob);
         hipFree(e->params);
         delete e;
+        sc_runtime_release(rt);
         return code;
     };
     // parameter arena: f32 tables + per-layer {bf16 matrices, f32 vectors}
@@ -248,7 +251,9 @@ extern "C" sc_status sc_encoder_destroy(sc_encoder* e) {
         if (slot.host) hipHostFree(slot.host);
         if (slot.done) hipEventDestroy(slot.done);
     }
+    sc_runtime* rt = e->rt;
     delete e;
+    sc_runtime_release(rt);
     return SC_OK;
 }
 

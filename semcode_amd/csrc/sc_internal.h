@@ -1,5 +1,6 @@
 // sc_internal.h -- handle structs shared by the host-side translation units.
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -21,6 +22,10 @@ sc_status sc_fail(sc_status code, const char* fmt, ...);
     } while (0)
 
 struct sc_runtime {
+    // Lifetime: the creator holds one reference, every index / encoder / communicator created on the runtime holds one more.
+    // sc_runtime_destroy drops the creator's; the stream and the struct go when the LAST reference does, so handles may be
+    // destroyed in any order (a garbage-collected Index after Runtime.close(): DESIGN.md section 9).
+    std::atomic<int> refs{1};
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -33,6 +38,8 @@ struct sc_runtime {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[SC_PROF_CLASSES];
 };
 
+void sc_runtime_retain(sc_runtime* rt);
+void sc_runtime_release(sc_runtime* rt);  // frees the runtime when the last reference is dropped
 void sc_prof_begin(sc_runtime* rt, int which, hipEvent_t* a, hipEvent_t* b);
 void sc_prof_end(sc_runtime* rt, int which, hipEvent_t a, hipEvent_t b);
 
@@ -61,14 +68,22 @@ struct sc_index {
     void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results)
     // IVF_FLAT (after sc_index_train): X / xnorm are stored list-major
     sc_index* quant = nullptr;                    // flat index over the nlist centroids (coarse quantizer)
-    uint32_t* perm = nullptr;                     // device [n]: stored position -> row id (insertion order)
-    uint32_t* inv = nullptr;                      // device [n]: row id -> stored position
+    uint32_t* perm = nullptr;                     // device [ivf_rows]: stored position -> row id (insertion order)
     int64_t* list_off = nullptr;                  // device [nlist + 1]
-    std::vector<uint32_t> inv_h;                  // host copy of inv (get_rows / overwrite)
+    std::vector<uint32_t> inv_h;                  // host [ivf_rows]: row id -> stored position (get_rows / overwrite / re-layout)
     std::vector<int64_t> list_off_h;
+    std::vector<int32_t> assign_h;                // host [ivf_rows]: list of every row in the lists (persistence, incremental upserts)
     int nlist_trained = 0;
+    // Upserts into a trained index do not drop the lists (Milvus: upsert into an indexed collection, milvus_store.py:128).
+    // Rows [0, ivf_rows) sit list-major at inv_h[row]; rows appended since sit behind them at position == row id; rows
+    // overwritten in place since are listed in dirty_rows (their list may have changed).  The next search first assigns the
+    // pending + dirty rows to the EXISTING centroids and re-orders the corpus once (sc_ivf_refresh_locked): no k-means.
+    int64_t ivf_rows = 0;
+    std::vector<int64_t> dirty_rows;
     void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
     int last_probed_lists = 0;
+    int64_t last_unique_rows = 0, last_streamed_rows = 0;  // sc_index_last_probe_stats
+    int last_groups = 0;
     int search_mode = 0;                          // 0 auto, 1 exact only, 2 batched whenever supported, 3 / 4 IVF probe per query / list-major whenever trained
     int last_path = 0;                            // 1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major
     int last_uncertified = 0;
@@ -84,6 +99,10 @@ sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int3
 bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, bool flat_is_batched);
 sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
+void sc_ivf_drop_lists_locked(sc_index* ix);    // drop lists without restoring the order (the rows are about to be discarded)
+sc_status sc_ivf_refresh_locked(sc_index* ix);  // fold rows upserted since the lists were built into them (no k-means)
+// stored position of row `r` (trained layout installed: ix->perm != nullptr)
+static inline int64_t sc_ivf_pos(const sc_index* ix, int64_t r) { return r < ix->ivf_rows ? (int64_t)ix->inv_h[(size_t)r] : r; }
 // upsert body shared by sc_index_put_rows{,_dev} and sc_encoder_embed_ids_into; caller holds ix->mu and has set the device
 sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on_device, const int64_t* rows, int64_t n, const char* who);
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe);

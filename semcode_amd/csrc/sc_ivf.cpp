@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <vector>
 
@@ -52,79 +53,106 @@ static sc_status assign_rows(sc_index* ix, const float* q_dev_tight, int64_t n, 
     return SC_OK;
 }
 
+namespace {
+struct Dev {  // device allocation released on scope exit unless handed over with take()
+    void* p = nullptr;
+    ~Dev() { hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    template <class T> T* take() { T* q = (T*)p; p = nullptr; return q; }
+};
+}  // namespace
+
+void sc_ivf_drop_lists_locked(sc_index* ix) {
+    if (ix->perm) hipStreamSynchronize(ix->rt->stream);
+    hipFree(ix->perm);
+    hipFree(ix->list_off);
+    ix->perm = nullptr;
+    ix->list_off = nullptr;
+    ix->inv_h.clear();
+    ix->list_off_h.clear();
+    ix->assign_h.clear();
+    ix->dirty_rows.clear();
+    ix->ivf_rows = 0;
+    ix->trained = false;
+    ix->shadow_rows = 0;
+}
+
+// Xo[pos] = X[g[pos]] for the n stored rows, into fresh corpus-sized buffers that replace X / xnorm on success.
+// Needs a second copy of the corpus for the duration of the move: the rebuildable buffers (bf16 shadow) are freed first.
+static sc_status ivf_move_rows_locked(sc_index* ix, const std::vector<uint32_t>& g, Dev& d_g) {
+    hipStream_t s = ix->rt->stream;
+    const int64_t n = ix->n;
+    SC_HIP(hipStreamSynchronize(s));
+    hipFree(ix->Xb);  // the layout changes: the shadow is rebuilt anyway
+    ix->Xb = nullptr;
+    ix->xb_cap = 0;
+    ix->shadow_rows = 0;
+    Dev nx, nn;
+    if (nx.alloc((size_t)ix->capacity * ix->ld * sizeof(float)) != hipSuccess || nn.alloc((size_t)ix->capacity * sizeof(float)) != hipSuccess ||
+        d_g.alloc((size_t)n * 4) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "ivf: hipMalloc of the re-ordered corpus (%lld rows x %d) failed", (long long)ix->capacity, ix->ld);
+    SC_HIP(hipMemcpyAsync(d_g.p, g.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    sc_launch_permute_rows(ix->X, ix->xnorm, (const uint32_t*)d_g.p, n, ix->ld, (float*)nx.p, (float*)nn.p, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipStreamSynchronize(s));
+    hipFree(ix->X);
+    hipFree(ix->xnorm);
+    ix->X = nx.take<float>();
+    ix->xnorm = nn.take<float>();
+    return SC_OK;
+}
+
 sc_status sc_ivf_untrain_locked(sc_index* ix) {
     if (!ix->perm) {
         ix->trained = false;
         return SC_OK;
     }
-    hipStream_t s = ix->rt->stream;
-    // Xo[row] = X[inv[row]]
-    float *nx = nullptr, *nn = nullptr;
-    hipError_t e = hipMalloc((void**)&nx, (size_t)ix->capacity * ix->ld * sizeof(float));
-    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "untrain: hipMalloc failed: %s", hipGetErrorString(e));
-    e = hipMalloc((void**)&nn, (size_t)ix->capacity * sizeof(float));
-    if (e != hipSuccess) {
-        hipFree(nx);
-        return sc_fail(SC_ERR_NOMEM, "untrain: hipMalloc failed: %s", hipGetErrorString(e));
+    if (ix->n > 0) {  // Xo[row] = X[position of row]
+        std::vector<uint32_t> g((size_t)ix->n);
+        for (int64_t r = 0; r < ix->n; ++r) g[(size_t)r] = (uint32_t)sc_ivf_pos(ix, r);
+        Dev d_g;
+        sc_status st = ivf_move_rows_locked(ix, g, d_g);
+        if (st) return st;  // nothing was changed: the lists stay valid
     }
-    sc_launch_permute_rows(ix->X, ix->xnorm, ix->inv, ix->n, ix->ld, nx, nn, s);
-    SC_HIP(hipStreamSynchronize(s));
-    hipFree(ix->X);
-    hipFree(ix->xnorm);
-    ix->X = nx;
-    ix->xnorm = nn;
-    hipFree(ix->perm);
-    hipFree(ix->inv);
-    hipFree(ix->list_off);
-    ix->perm = ix->inv = nullptr;
-    ix->list_off = nullptr;
-    ix->inv_h.clear();
-    ix->list_off_h.clear();
-    ix->trained = false;
-    ix->shadow_rows = 0;
+    sc_ivf_drop_lists_locked(ix);
     return SC_OK;
 }
 
-// Given a quantizer already installed in ix->quant and the list of every row (insertion order), re-order the corpus list-major.
-static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, const std::vector<int32_t>& assign) {
+// Given a quantizer already installed in ix->quant and the list of every stored row (by row id), re-order the corpus list-major
+// (stable by row id inside a list).  Works from whatever layout is current: insertion order (fresh build) or an older list-major
+// layout with appended rows behind it (incremental refresh).  Nothing of the index is modified unless every step succeeded.
+static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<int32_t>&& assign) {
     hipStream_t s = ix->rt->stream;
     const int64_t n = ix->n;
-    const int ld = ix->ld;
     std::vector<int64_t> off((size_t)nlist + 1, 0);
     for (int64_t i = 0; i < n; ++i) off[(size_t)assign[(size_t)i] + 1]++;
     for (int c = 0; c < nlist; ++c) off[(size_t)c + 1] += off[(size_t)c];
-    std::vector<uint32_t> perm((size_t)n), inv((size_t)n);
+    std::vector<uint32_t> perm((size_t)n), inv((size_t)n), g((size_t)n);
     {
         std::vector<int64_t> cur(off.begin(), off.end() - 1);
         for (int64_t i = 0; i < n; ++i) {
             const int64_t pos = cur[(size_t)assign[(size_t)i]]++;
             perm[(size_t)pos] = (uint32_t)i;
             inv[(size_t)i] = (uint32_t)pos;
+            g[(size_t)pos] = ix->perm ? (uint32_t)sc_ivf_pos(ix, i) : (uint32_t)i;  // where row i sits now
         }
     }
-    float *nx = nullptr, *nn = nullptr;
-    hipError_t e = hipMalloc((void**)&nx, (size_t)ix->capacity * ld * sizeof(float));
-    if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "train: hipMalloc list-major corpus failed: %s", hipGetErrorString(e));
-    e = hipMalloc((void**)&nn, (size_t)ix->capacity * sizeof(float));
-    if (e != hipSuccess) {
-        hipFree(nx);
-        return sc_fail(SC_ERR_NOMEM, "train: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    SC_HIP(hipMalloc((void**)&ix->perm, (size_t)n * 4));
-    SC_HIP(hipMalloc((void**)&ix->inv, (size_t)n * 4));
-    SC_HIP(hipMalloc((void**)&ix->list_off, (size_t)(nlist + 1) * 8));
-    SC_HIP(hipMemcpyAsync(ix->perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    SC_HIP(hipMemcpyAsync(ix->inv, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    SC_HIP(hipMemcpyAsync(ix->list_off, off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
-    sc_launch_permute_rows(ix->X, ix->xnorm, ix->perm, n, ld, nx, nn, s);
-    SC_HIP(hipGetLastError());
-    SC_HIP(hipStreamSynchronize(s));
-    hipFree(ix->X);
-    hipFree(ix->xnorm);
-    ix->X = nx;
-    ix->xnorm = nn;
+    Dev d_perm, d_off, d_g;
+    if (d_perm.alloc((size_t)n * 4) != hipSuccess || d_off.alloc((size_t)(nlist + 1) * 8) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "ivf: hipMalloc of the list tables failed");
+    SC_HIP(hipMemcpyAsync(d_perm.p, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(d_off.p, off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, s));
+    sc_status st = ivf_move_rows_locked(ix, g, d_g);  // synchronises: the uploads above are complete as well
+    if (st) return st;
+    hipFree(ix->perm);
+    hipFree(ix->list_off);
+    ix->perm = d_perm.take<uint32_t>();
+    ix->list_off = d_off.take<int64_t>();
     ix->inv_h.swap(inv);
     ix->list_off_h.swap(off);
+    ix->assign_h = std::move(assign);
+    ix->ivf_rows = n;
+    ix->dirty_rows.clear();
     ix->nlist_trained = nlist;
     ix->shadow_rows = 0;
     ix->uncert_frac = -1.0;
@@ -132,14 +160,52 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, const std::ve
     return SC_OK;
 }
 
+// Incremental upsert: rows appended or overwritten since the lists were built are assigned to the EXISTING centroids and the
+// corpus is re-ordered once (one pass over the corpus, no k-means).  The result is exactly what sc_index_assign_lists would
+// build from scratch for these centroids.  Called at the start of every search; caller holds ix->mu.
+sc_status sc_ivf_refresh_locked(sc_index* ix) {
+    if (!ix->perm || !ix->quant || (ix->ivf_rows == ix->n && ix->dirty_rows.empty())) return SC_OK;
+    hipStream_t s = ix->rt->stream;
+    std::vector<int64_t> rows(ix->dirty_rows);
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    for (int64_t r = ix->ivf_rows; r < ix->n; ++r) rows.push_back(r);
+    std::vector<int32_t> assign(ix->assign_h);
+    assign.resize((size_t)ix->n, -1);
+    bool changed = ix->n > ix->ivf_rows;
+    const int64_t CH = 65536;
+    Dev d_pos, d_tight;
+    const int64_t chmax = std::min<int64_t>(CH, (int64_t)rows.size());
+    if (d_pos.alloc((size_t)chmax * 8) != hipSuccess || d_tight.alloc((size_t)chmax * ix->dim * 4) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "ivf refresh: hipMalloc failed");
+    std::vector<int64_t> pos((size_t)chmax);
+    std::vector<int32_t> out;
+    for (int64_t c0 = 0; c0 < (int64_t)rows.size(); c0 += CH) {
+        const int64_t m = std::min<int64_t>(CH, (int64_t)rows.size() - c0);
+        for (int64_t i = 0; i < m; ++i) pos[(size_t)i] = sc_ivf_pos(ix, rows[(size_t)(c0 + i)]);
+        SC_HIP(hipMemcpyAsync(d_pos.p, pos.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
+        sc_launch_rows_to_sample(ix->X, ix->ld, ix->dim, (const int64_t*)d_pos.p, m, (float*)d_tight.p, s);
+        SC_HIP(hipGetLastError());
+        sc_status st = assign_rows(ix, (const float*)d_tight.p, m, out);  // synchronises
+        if (st) return st;
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t r = rows[(size_t)(c0 + i)];
+            if (assign[(size_t)r] != out[(size_t)i]) changed = true;
+            assign[(size_t)r] = out[(size_t)i];
+        }
+    }
+    if (!changed) {  // overwritten rows all stayed in their lists: nothing moves
+        ix->dirty_rows.clear();
+        return SC_OK;
+    }
+    return ivf_install_lists_locked(ix, ix->nlist_trained, std::move(assign));
+}
+
 // Quantizer installed in ix->quant: assign every stored row to its nearest centroid and re-order the corpus list-major.
 static sc_status ivf_assign_all_and_install_locked(sc_index* ix, int nlist) {
     hipStream_t s = ix->rt->stream;
     const int64_t n = ix->n;
-    struct Dev {
-        void* p = nullptr;
-        ~Dev() { hipFree(p); }
-    } d_tight;
+    Dev d_tight;
     const float* all_tight = ix->X;
     if (ix->ld != ix->dim) {
         SC_HIP(hipMalloc(&d_tight.p, (size_t)n * ix->dim * 4));
@@ -149,7 +215,7 @@ static sc_status ivf_assign_all_and_install_locked(sc_index* ix, int nlist) {
     std::vector<int32_t> assign;
     sc_status st = assign_rows(ix, all_tight, n, assign);
     if (st) return st;
-    return ivf_install_lists_locked(ix, nlist, assign);
+    return ivf_install_lists_locked(ix, nlist, std::move(assign));
 }
 
 extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) {
@@ -171,10 +237,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
     // ---- sample (tight [ns, dim]) and initial centroids
     std::vector<int64_t> srows((size_t)ns);
     for (int64_t i = 0; i < ns; ++i) srows[(size_t)i] = (int64_t)(((__int128)i * n) / ns);
-    struct Dev {
-        void* p = nullptr;
-        ~Dev() { hipFree(p); }
-    } d_srows, d_sample, d_cinit, d_members, d_moff, d_cnew, d_tight;
+    Dev d_srows, d_sample, d_cinit, d_members, d_moff, d_cnew;
     SC_HIP(hipMalloc(&d_srows.p, (size_t)ns * 8));
     SC_HIP(hipMalloc(&d_sample.p, (size_t)ns * dim * 4));
     SC_HIP(hipMemcpyAsync(d_srows.p, srows.data(), (size_t)ns * 8, hipMemcpyHostToDevice, s));
@@ -548,6 +611,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     }
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;
+    ix->last_groups = G;
+    for (size_t g = 0; g < sr.size(); g += 2) ix->last_streamed_rows += sr[g + 1] - sr[g];
+    for (int l = 0; l < nlist; ++l)
+        if (start[(size_t)l + 1] > start[(size_t)l]) ix->last_unique_rows += ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
     return SC_OK;
 }
 
@@ -556,11 +623,10 @@ extern "C" sc_status sc_index_ivf_assignments(sc_index* ix, int32_t* out) {
     if (!ix || !out) return sc_fail(SC_ERR_INVALID, "sc_index_ivf_assignments: NULL argument");
     std::lock_guard<std::mutex> g(ix->mu);
     if (!ix->trained) return sc_fail(SC_ERR_STATE, "sc_index_ivf_assignments: the index is not trained");
-    for (int64_t i = 0; i < ix->n; ++i) {
-        const int64_t pos = ix->inv_h[(size_t)i];
-        const auto it = std::upper_bound(ix->list_off_h.begin(), ix->list_off_h.end(), pos);
-        out[i] = (int32_t)(it - ix->list_off_h.begin()) - 1;
-    }
+    SC_HIP(hipSetDevice(ix->rt->device));
+    sc_status st = sc_ivf_refresh_locked(ix);  // rows upserted since the build get their list first
+    if (st) return st;
+    memcpy(out, ix->assign_h.data(), (size_t)ix->n * sizeof(int32_t));
     return SC_OK;
 }
 
@@ -615,6 +681,11 @@ extern "C" sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* cent
     if (!ix->trained || !ix->quant) {
         if (nlist) *nlist = 0;
         return SC_OK;
+    }
+    SC_HIP(hipSetDevice(ix->rt->device));
+    {
+        sc_status st = sc_ivf_refresh_locked(ix);
+        if (st) return st;
     }
     if (nlist) *nlist = ix->nlist_trained;
     if (centroids) {

@@ -96,13 +96,27 @@ class MI355XEmbeddings:
 
     def __init__(self, model: Optional[str] = None, *, cfg: Optional[dict] = None, weights: "np.ndarray | str | Path | None" = None,
                  vocab: "dict | str | Path | None" = None, device: Optional[int] = None, max_tokens: Optional[int] = None,
-                 normalize: bool = False, batch_size: int = 256, runtime: Any = None, synth_seed: int = 0) -> None:
+                 normalize: bool = False, batch_size: int = 256, runtime: Any = None, synth_seed: int = 0,
+                 allow_synthetic: Optional[bool] = None) -> None:
         from .. import _native  # raises loudly when libsemcode_hip.so is missing: there is no CPU fallback
 
         settings = _resolve_settings()
         self.model = model or getattr(settings, "embedding_model", None)
         self.max_tokens = int(max_tokens or getattr(settings, "mi355x_max_tokens", 512))
         self.batch_size = int(batch_size)
+        # Like the reference's llama.cpp branch, which refuses to start without a model path (providers.py:77-81), a client
+        # without weights or without a vocabulary is an error: random-init weights and the hash tokenizer produce vectors that
+        # index and search without any error and mean nothing.  Benchmarks and tests opt in explicitly.
+        if allow_synthetic is None:
+            allow_synthetic = bool(getattr(settings, "mi355x_allow_synthetic", False))
+        weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
+        vocab = vocab if vocab is not None else getattr(settings, "mi355x_vocab_path", None)
+        if weights is None and not allow_synthetic:
+            raise ValueError("Set SEMCODE_MI355X_WEIGHTS_PATH (.safetensors or .npy blob) when using the mi355x embedding provider "
+                             "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for random-init benchmark weights).")
+        if vocab is None and not allow_synthetic:
+            raise ValueError("Set SEMCODE_MI355X_VOCAB_PATH (vocab.txt of the model) when using the mi355x embedding provider "
+                             "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for the hash-tokenizer stand-in).")
         self._native = _native
         self._cfg = dict(_native.BERT_BASE)
         self._cfg.update(cfg or {})
@@ -110,13 +124,11 @@ class MI355XEmbeddings:
         self._fast_tokenizer: Any = None
         self._owns_runtime = False  # an explicit runtime is the caller's; the default one is shared with the vector store
         self._runtime = runtime or _native.shared_runtime(int(device if device is not None else getattr(settings, "mi355x_device", 0)))
-        weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
         if isinstance(weights, (str, Path)):
             weights = load_weight_blob(weights, self._cfg["layers"], self._cfg)
         if weights is None:
             log.warning("mi355x embeddings: no weights configured (SEMCODE_MI355X_WEIGHTS_PATH); using random-init weights seed=%d", synth_seed)
         self._encoder = _native.Encoder(self._runtime, self._cfg, weights=weights, normalize=normalize, synth_seed=synth_seed)
-        vocab = vocab if vocab is not None else getattr(settings, "mi355x_vocab_path", None)
         if vocab is None:
             log.warning("mi355x embeddings: no vocab.txt configured (SEMCODE_MI355X_VOCAB_PATH); using the hash tokenizer stand-in")
             self.tokenizer: Any = HashTokenizer(self._cfg["vocab"])
@@ -231,8 +243,13 @@ class EmbeddingProviderFactory:
             model_path = settings.embedding_llamacpp_model_path
             if not model_path:
                 raise ValueError("Set SEMCODE_EMBEDDING_LLAMACPP_MODEL_PATH when using the llama.cpp embedding provider.")
-            return LlamaCppEmbeddings(model_path=str(model_path), n_ctx=settings.embedding_llamacpp_n_ctx,
-                                      n_threads=settings.embedding_llamacpp_n_threads, n_batch=settings.embedding_llamacpp_batch_size,
-                                      n_gpu_layers=0, verbose=False)
+            # every argument the reference passes (providers.py:85-99): this branch is untouched by the MI355X backend and a
+            # checkout that selects it must construct the very same client
+            llama_kwargs: dict[str, Any] = {"model_path": str(model_path), "n_ctx": settings.embedding_llamacpp_n_ctx,
+                                            "n_threads": settings.embedding_llamacpp_n_threads, "n_parts": -1, "seed": 0, "f16_kv": True,
+                                            "logits_all": False, "vocab_only": False, "use_mlock": False,
+                                            "n_batch": settings.embedding_llamacpp_batch_size, "n_gpu_layers": 0, "verbose": False,
+                                            "device": "cpu"}
+            return LlamaCppEmbeddings(**llama_kwargs)
 
         raise NotImplementedError(f"Embedding provider not yet supported: {provider_name}")

@@ -7,7 +7,7 @@ seams usable (and testable) without pydantic_settings, which is absent in the bu
 
 Backend-specific keys ride on the reference's extra="allow" (settings.py:36):
     mi355x_device, mi355x_metric, mi355x_index_type, mi355x_nlist, mi355x_nprobe,
-    mi355x_weights_path, mi355x_vocab_path, mi355x_max_tokens, mi355x_store_path, mi355x_ingest_batch
+    mi355x_weights_path, mi355x_vocab_path, mi355x_allow_synthetic, mi355x_max_tokens, mi355x_store_path, mi355x_ingest_batch
 """
 from __future__ import annotations
 
@@ -42,6 +42,7 @@ _DEFAULTS: dict[str, Any] = {
     "mi355x_nprobe": 16,              # milvus_store.py:144
     "mi355x_weights_path": None,
     "mi355x_vocab_path": None,
+    "mi355x_allow_synthetic": False,  # random-init weights / hash tokenizer when the two paths above are unset (benchmarks only)
     "mi355x_max_tokens": 512,
     "mi355x_store_path": None,
     "mi355x_ingest_batch": 256,       # chunks per embed+upsert batch of services.indexer.ingest_chunks

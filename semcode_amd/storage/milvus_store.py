@@ -88,6 +88,8 @@ class SearchResult(list):
 class MilvusVectorStore:
     """Thin wrapper with the reference's surface, storing vectors on the MI355X."""
 
+    RETRAIN_GROWTH = 2.0  # re-run k-means when the collection has this many times the rows its centroids were trained on
+
     def __init__(self, collection_name: str = "semcode_chunks", dim: Optional[int] = None, *, metric: Optional[str] = None,
                  index_type: Optional[str] = None, nlist: Optional[int] = None, nprobe: Optional[int] = None,
                  device: Optional[int] = None, runtime: Any = None, index_factory: Optional[Callable[..., Any]] = None) -> None:
@@ -112,7 +114,12 @@ class MilvusVectorStore:
         self._paths: List[str] = []
         self._languages: List[str] = []
         self._row_of: dict[str, int] = {}
-        self._needs_train = False  # IVF_FLAT lists are (re)built lazily before a search, like Milvus' background index build
+        # IVF_FLAT lists are built lazily before a search (Milvus' background index build).  Once built they are kept across
+        # upserts: the device index assigns upserted rows to the existing centroids at the next search (no k-means, like
+        # Collection.upsert into an indexed collection, milvus_store.py:128).  k-means runs again only on build_index() or when
+        # the collection has grown to RETRAIN_GROWTH x the row count the centroids were trained on.
+        self._needs_train = False
+        self._trained_rows = 0
 
     # ------------------------------------------------------------------ lifecycle
     def connect(self) -> None:
@@ -174,47 +181,32 @@ class MilvusVectorStore:
             inserted += len(batch)
             if progress:
                 progress(inserted, total)
-        self._needs_train = True
 
     def _upsert_batch(self, batch: Sequence[EmbeddingPayload]) -> None:
         vectors = np.asarray([p.vector for p in batch], dtype=np.float32)
         if vectors.ndim != 2 or vectors.shape[1] != self.dim:
             raise ValueError(f"embedding dimension mismatch: collection dim={self.dim}, got array of shape {vectors.shape}")
         # a primary key repeated inside one batch: the last occurrence wins (upsert semantics)
-        last = {p.id: i for i, p in enumerate(batch)}
-        new_idx, new_rows, old_idx, old_rows = [], [], [], []
-        next_row = len(self._ids)
-        for pk, i in last.items():
-            row = self._row_of.get(pk)
-            if row is None:
-                new_idx.append(i)
-                new_rows.append(next_row)
-                next_row += 1
-            else:
-                old_idx.append(i)
-                old_rows.append(row)
-        order = np.argsort(new_idx) if new_idx else []
-        new_idx = [new_idx[j] for j in order]
-        if new_idx:
-            self._collection.add(vectors[new_idx])
-        if old_idx:
-            self._collection.overwrite(vectors[old_idx], np.asarray(old_rows, dtype=np.int64))
-        for i in new_idx:
-            p = batch[i]
-            self._row_of[p.id] = len(self._ids)
-            self._ids.append(p.id)
-            self._repos.append(p.metadata.get("repo", ""))
-            self._paths.append(p.metadata.get("path", ""))
-            self._languages.append(p.metadata.get("language", ""))
-            self._texts.append(p.text)
-            self._metadata.append(p.metadata)
-        for i, row in zip(old_idx, old_rows):
-            p = batch[i]
-            self._repos[row] = p.metadata.get("repo", "")
-            self._paths[row] = p.metadata.get("path", "")
-            self._languages[row] = p.metadata.get("language", "")
-            self._texts[row] = p.text
-            self._metadata[row] = p.metadata
+        keep = sorted({p.id: i for i, p in enumerate(batch)}.values())
+        ids = [batch[i].id for i in keep]
+        rows = self.plan_rows(ids)
+        # one native call per batch: it validates that every row is an existing row or the next free one, so a drift between
+        # the device index and the host columns fails loudly; the columns are committed only after it has succeeded
+        self._put_rows(vectors[keep], rows)
+        self.commit_rows(ids, rows, [batch[i].text for i in keep], [batch[i].metadata for i in keep])
+
+    def _put_rows(self, vectors: np.ndarray, rows: np.ndarray) -> None:
+        ix = self._collection
+        if hasattr(ix, "put_rows"):
+            ix.put_rows(vectors, rows)
+        else:  # an index_factory object with only the add / overwrite pair
+            new = rows >= len(self._ids)
+            if new.any():
+                ix.add(vectors[new])
+            if (~new).any():
+                ix.overwrite(vectors[~new], rows[~new])
+        if hasattr(ix, "__len__") and len(ix) != max(len(self._ids), int(rows.max()) + 1):
+            raise RuntimeError(f"vector index holds {len(ix)} rows, the collection's columns expect {max(len(self._ids), int(rows.max()) + 1)}")
 
     # ------------------------------------------------------------------ array fast paths
     def plan_rows(self, ids: Sequence[str]) -> np.ndarray:
@@ -248,7 +240,12 @@ class MilvusVectorStore:
                 self._repos[row], self._paths[row], self._languages[row] = cols
                 self._texts[row] = text
                 self._metadata[row] = meta
-        self._needs_train = True
+        self._note_growth()
+
+    def _note_growth(self) -> None:
+        n = len(self._ids)
+        if self._trained_rows == 0 or n >= self.RETRAIN_GROWTH * self._trained_rows:
+            self._needs_train = True
 
     def upsert_arrays(self, ids: Sequence[str], vectors: Any, texts: Sequence[str], metadatas: Sequence[dict],
                       progress: Optional[Callable[[int, int], None]] = None) -> None:
@@ -275,7 +272,7 @@ class MilvusVectorStore:
             b_ids = [ids[i] for i in keep]
             with self._lock:
                 rows = self.plan_rows(b_ids)
-                self._collection.put_rows(vec[keep], rows)
+                self._put_rows(vec[keep], rows)
                 self.commit_rows(b_ids, rows, [texts[i] for i in keep], [metadatas[i] for i in keep])
             done = stop
             if progress:
@@ -290,6 +287,9 @@ class MilvusVectorStore:
             raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
         with self._lock:
             rows = self.plan_rows(ids)
+            # argument errors surface here, before anything is committed; with wait=False a failure of the enqueued device
+            # work is reported by embedding_client.wait() (services.ingest_chunks calls it before it returns) -- the rows of
+            # that batch then hold undefined vectors and the caller must upsert them again
             embedding_client.embed_ids_into(self, token_ids, lens, rows, wait=wait)
             self.commit_rows(ids, rows, texts, metadatas)
 
@@ -318,13 +318,23 @@ class MilvusVectorStore:
             raise RuntimeError("Milvus collection is not initialized. Call connect() first.")
         with self._lock:
             if self.index_type == "IVF_FLAT" and hasattr(self._collection, "train") and len(self._ids) > 0:
-                self._collection.train(niter=niter)
+                self._train(niter)
             self._needs_train = False
+
+    def _train(self, niter: int) -> None:
+        if hasattr(self._collection, "release_scratch"):
+            self._collection.release_scratch()  # training needs a second copy of the corpus: drop what can be rebuilt first
+        self._collection.train(niter=niter)
+        self._trained_rows = len(self._ids)
 
     def _maybe_train(self) -> None:
         # faiss' rule of thumb: at least 39 points per centroid, otherwise the exhaustive scan is used (exact results)
         if self._needs_train and self.index_type == "IVF_FLAT" and hasattr(self._collection, "train") and len(self._ids) >= 39 * self.nlist:
-            self._collection.train(niter=10)
+            try:
+                self._train(10)
+            except Exception as exc:  # e.g. no room for the second corpus copy: serve exact exhaustive results instead of failing every search
+                log.warning("ivf_train_failed rows=%d nlist=%d: %s -- answering with the exhaustive scan until build_index() succeeds",
+                            len(self._ids), self.nlist, exc)
         self._needs_train = False
 
     def hits_for(self, dist: np.ndarray, rows: np.ndarray) -> SearchResult:
@@ -414,6 +424,7 @@ class MilvusVectorStore:
                 if cent.size == tn * self.dim and assign.size == n:
                     self._collection.set_ivf(cent.reshape(tn, self.dim), assign)
                     self._needs_train = False
+                    self._trained_rows = n
 
     def __iter__(self) -> Iterator:  # pragma: no cover - convenience
         return iter(self._ids)

@@ -19,7 +19,7 @@ SMALL = dict(vocab=2000, hidden=128, layers=2, heads=2, ffn=256, max_pos=128)
 
 
 def test_concurrent_search_upsert_embed():
-    emb = MI355XEmbeddings(cfg=SMALL, synth_seed=7)
+    emb = MI355XEmbeddings(cfg=SMALL, synth_seed=7, allow_synthetic=True)
     store = MilvusVectorStore(dim=128, metric="COSINE", index_type="FLAT")
     store.connect()
     rng = np.random.default_rng(0)

@@ -48,6 +48,9 @@ class FakeIndex:
     def get_rows(self, first, n):
         return self.X[first:first + n].copy()
 
+    def __len__(self):
+        return len(self.X)
+
     def search(self, q, k=10, nprobe=16):
         s = q @ self.X.T
         order = np.argsort(-s, axis=1, kind="stable")[:, :k]
@@ -88,7 +91,8 @@ def test_upsert_progress_protocol_300_by_128():
     seen = []
     s.upsert_embeddings([payload(i, np.eye(4)[i % 4]) for i in range(300)], progress=lambda a, b: seen.append((a, b)))
     assert seen == [(0, 300), (128, 300), (256, 300), (300, 300)]
-    assert [c for c in s._collection.calls] == [("add", 128), ("add", 128), ("add", 44)]
+    # one native call per reference batch (milvus_store.py:119-130), rows = the next free ones
+    assert [c for c in s._collection.calls] == [("put_rows", list(range(0, 128))), ("put_rows", list(range(128, 256))), ("put_rows", list(range(256, 300)))]
     seen.clear()
     s.upsert_embeddings([], progress=lambda a, b: seen.append((a, b)))
     assert seen == [(0, 0)]
@@ -100,7 +104,7 @@ def test_upsert_replaces_by_primary_key():
     s.upsert_embeddings([payload(0, [1, 0, 0, 0]), payload(1, [0, 1, 0, 0])])
     s.upsert_embeddings([payload(1, [0, 0, 1, 0]), payload(2, [0, 0, 0, 1]), payload(2, [0, 0, 0, 2])])
     assert len(s) == 3
-    assert ("overwrite", [1]) in s._collection.calls
+    assert ("put_rows", [1, 2]) in s._collection.calls  # existing row 1 replaced, row 2 appended, in one call
     assert s._collection.X.tolist() == [[1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 2]]  # last duplicate in a batch wins
     hits = next(iter(s.search([0, 0, 1, 0], top_k=1)))
     assert hits[0].id == "id1" and hits[0].entity.get("path") == "src/f1.py"

@@ -32,6 +32,11 @@ class Chunk:
 
 def test_factory_returns_device_provider(rt, monkeypatch):
     monkeypatch.setenv("SEMCODE_EMBEDDING_PROVIDER", "mi355x")
+    # no weights / vocabulary configured: an error like the reference's unset llama.cpp model path (providers.py:77-81), never
+    # a silently random model
+    with pytest.raises(ValueError, match="SEMCODE_MI355X_WEIGHTS_PATH"):
+        EmbeddingProviderFactory.create(provider="mi355x")
+    monkeypatch.setattr(settings, "mi355x_allow_synthetic", True)  # the explicit opt-in benchmarks use (SEMCODE_MI355X_ALLOW_SYNTHETIC=1)
     emb = EmbeddingProviderFactory.create(provider="mi355x")
     assert isinstance(emb, MI355XEmbeddings) and emb.dimension == 768
     v = emb.embed_query("def greet(name): return name")
@@ -40,7 +45,7 @@ def test_factory_returns_device_provider(rt, monkeypatch):
 
 
 def test_embed_store_search_round_trip(rt):
-    emb = MI355XEmbeddings(cfg=SMALL, runtime=rt, synth_seed=3)
+    emb = MI355XEmbeddings(cfg=SMALL, runtime=rt, synth_seed=3, allow_synthetic=True)
     root = Path("/w/demo")
     texts = [f"def f{i}(x):\n    return x + {i}  # helper number {i}" for i in range(150)]
     chunks = [Chunk(t, root / "src" / f"m{i % 7}.py", "python", i + 1, i + 3) for i, t in enumerate(texts)]
@@ -137,7 +142,7 @@ def test_provider_with_vocab_uses_native_tokenizer(rt, tmp_path):
     words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "def", "return", "x", "y", "f", "(", ")", ":", "+", "1", "##1", "caf", "##e"]
     vocab = tmp_path / "vocab.txt"
     vocab.write_text("\n".join(words) + "\n", encoding="utf-8")
-    emb = MI355XEmbeddings(cfg=dict(SMALL, vocab=len(words)), vocab=vocab, runtime=rt, synth_seed=1)
+    emb = MI355XEmbeddings(cfg=dict(SMALL, vocab=len(words)), vocab=vocab, runtime=rt, synth_seed=1, allow_synthetic=True)
     assert emb._fast_tokenizer is not None
     texts = ["def f(x): return x + 1", "def f(y): return y + 11", "café x"]  # the third goes through the Python fallback
     ids, lens = emb.tokenize(texts)
@@ -185,7 +190,7 @@ def test_ingest_chunks_equals_reference_loops(monkeypatch):
     """The fused device-to-device ingest stores exactly what _build_payloads + upsert_embeddings store
     (indexer.py:94-114), vectors bit for bit when both use the same batches."""
     monkeypatch.setattr(settings, "mi355x_ingest_batch", 64, raising=False)
-    emb = MI355XEmbeddings(cfg=SMALL, synth_seed=3)  # default runtime: shared with the stores below
+    emb = MI355XEmbeddings(cfg=SMALL, synth_seed=3, allow_synthetic=True)  # default runtime: shared with the stores below
     root = Path("/w/demo")
     texts = [("def f%d(x):\n    return x + %d  # helper number %d " % (i, i, i)) * (1 + i % 5) for i in range(150)]
     chunks = [Chunk(t, root / "src" / f"m{i}.py", "python", i + 1, i + 3) for i, t in enumerate(texts)]

@@ -66,12 +66,20 @@ def test_factory_dispatch_and_error_types(monkeypatch):
     # or the RuntimeError of providers.py:73-76 when it is not
     with pytest.raises((ValueError, RuntimeError)):
         EmbeddingProviderFactory.create(provider="llamacpp")
-    # the MI355X provider needs the device: without one the error surfaces (no silent CPU fallback)
+    # the MI355X provider without weights / vocabulary configured: ValueError, as for the unset llama.cpp path
+    monkeypatch.delenv("SEMCODE_MI355X_WEIGHTS_PATH", raising=False)
+    monkeypatch.delenv("SEMCODE_MI355X_ALLOW_SYNTHETIC", raising=False)
+    with pytest.raises(ValueError, match="SEMCODE_MI355X_WEIGHTS_PATH"):
+        EmbeddingProviderFactory.create(provider="mi355x")
+    # and it needs the device: without one the error surfaces (no silent CPU fallback)
     import torch
 
     if not torch.cuda.is_available():
         from semcode_amd import _native
 
+        from semcode_amd.settings import settings
+
+        monkeypatch.setattr(settings, "mi355x_allow_synthetic", True)  # the settings object is read once at import, like the reference's
         with pytest.raises(_native.ScError):
             EmbeddingProviderFactory.create(provider="mi355x")
 
