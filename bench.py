@@ -82,22 +82,31 @@ def timed(ctx, fn, nsteps):
     """EXACTLY nsteps calls of fn, bracketed by barrier + synchronize on both sides; max over ranks."""
     import torch
 
+    def barrier():
+        if ctx.comm is not None:
+            ctx.comm.allreduce_max(0.0)  # an RCCL all-reduce on the runtime's stream + its synchronisation
+        else:
+            ctx.dist.barrier()
+
     torch.cuda.synchronize()
     if ctx.world > 1:
-        ctx.dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(nsteps):
         fn()
     torch.cuda.synchronize()
     if ctx.world > 1:
-        ctx.dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if ctx.world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
-        ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if ctx.comm is not None:
+            dt = ctx.comm.allreduce_max(dt)
+        else:
+            t = torch.tensor([dt], dtype=torch.float64)
+            ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)  # control group (gloo): a host double
+            dt = float(t.item())
     return dt
 
 
@@ -165,10 +174,12 @@ def cpu_baseline_embed(args) -> dict:
     from oracle import bert_oracle as bo
     from oracle import bert_torch as bt
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from oracle.sc_oracle import host_cores
+
+    cores = host_cores()  # affinity mask capped by the cgroup CPU quota
     cfg = dict(bo.BERT_BASE)
     blob = bo.make_blob(cfg, 0, "bench")
-    n = args.batch if cores >= 32 else 32
+    n = args.batch if cores >= 64 else 64
     rng = np.random.default_rng(1)
     ids = rng.integers(1000, 30000, size=(n, args.seq)).astype(np.int32)
     lens = np.full(n, args.seq, np.int32)
@@ -198,14 +209,27 @@ def bench_scan(ctx, args) -> dict:
     if world > 1:
         all_d = torch.empty((world, Q, k), dtype=torch.float32, device=dev)
         all_r = torch.empty((world, Q, k), dtype=torch.int64, device=dev)
+        if ctx.comm is not None:
+            from semcode_amd.storage.sharded import ShardedSearcher
+
+            searcher = ShardedSearcher(ix, args.metric_type, comm=ctx.comm)
     rt.synchronize()
 
     def step(nq=Q):
+        if world > 1 and ctx.comm is not None:
+            # the product path (storage.sharded.ShardedSearcher.search_dev): shard search + the ONE exchange step (RCCL all-gather
+            # of every shard's [Q,k] over xGMI, issued by libsemcode_hip on its stream), then the host merge on rank 0
+            searcher.search_dev(q.data_ptr(), nq, k, all_d.data_ptr(), all_r.data_ptr())
+            if rank == 0:
+                gd = all_d.view(-1)[: world * nq * k].view(world, nq, k)  # the gathered arrays are [world, nq, k] from the buffers' start
+                gr = all_r.view(-1)[: world * nq * k].view(world, nq, k)
+                return _native.topk_merge_host(args.metric_type, gd.cpu().numpy(), gr.cpu().numpy())
+            return None
         ix.search_dev(q.data_ptr(), nq, k, out_d.data_ptr(), out_r.data_ptr())
-        if world > 1:  # the one exchange step of the path: per-shard [Q,k] -> every rank, then host merge
-            if ctx.backend == "nccl":
-                ctx.dist.all_gather_into_tensor(all_d, out_d)
-                ctx.dist.all_gather_into_tensor(all_r, out_r)
+        if world > 1:  # no native communicator: torch.distributed carries the exchange
+            if ctx.nccl_group is not None:
+                ctx.dist.all_gather_into_tensor(all_d, out_d, group=ctx.nccl_group)
+                ctx.dist.all_gather_into_tensor(all_r, out_r, group=ctx.nccl_group)
                 gd, gr = all_d, all_r
             else:  # rehearsal backend: gather on the host
                 hd, hr = out_d.cpu(), out_r.cpu()
@@ -320,7 +344,7 @@ def cpu_baseline_scan(args) -> dict:
     fmaf-chain C port that defines the bit-exact arithmetic (the parity oracle, OpenMP over rows) is timed beside it."""
     from oracle import sc_oracle as orc
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = orc.host_cores()  # affinity mask capped by the cgroup CPU quota
     rows, nq = 1_000_000, args.queries
     X = orc.synth(rows, args.dim, seed=0)
     Q = orc.synth(nq, args.dim, seed=1)
@@ -445,17 +469,46 @@ def main() -> None:
     ctx.dev = torch.device("cuda", local)
     ctx.dist = None
     ctx.backend = backend
-    if ctx.world > 1:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=ctx.dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
-        ctx.dist = dist
+    ctx.comm = None
+    ctx.nccl_group = None
+    ctx.collective = None
     stream = torch.cuda.Stream(device=ctx.dev)
     ctx.rt = _native.Runtime(device=local, stream=stream.cuda_stream)
     info = ctx.rt.device_info()
+    if ctx.world > 1:
+        import torch.distributed as dist
+
+        # control plane: a gloo group started from the launcher's MASTER_ADDR / MASTER_PORT.  It carries the 128-byte RCCL
+        # rendezvous id (and, for the rehearsal backend, the exchange itself).  The data path's collective is the native
+        # communicator: RCCL bound by libsemcode_hip, issued on the runtime's stream (include/semcode_hip.h, sc_comm_*).
+        dist.init_process_group("gloo")
+        ctx.dist = dist
+        if backend == "nccl":
+            from semcode_amd.storage.sharded import make_comm
+
+            err = ""
+            try:
+                ctx.comm = make_comm(ctx.rt)
+                ctx.comm.allreduce_max(0.0)
+            except Exception as exc:  # every rank must take the same path: agree on the outcome first
+                err = f"{type(exc).__name__}: {exc}"
+                ctx.comm = None
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                ctx.collective = "RCCL all-gather behind the C ABI (sc_index_search_sharded_dev), one grouped launch per step"
+            else:
+                # stated loudly in the output line: the exchange then goes through torch.distributed's RCCL binding instead
+                if ctx.comm is not None:
+                    ctx.comm.close()
+                    ctx.comm = None
+                errs = [None] * ctx.world
+                dist.all_gather_object(errs, err)
+                ctx.nccl_group = dist.new_group(backend="nccl", device_id=ctx.dev)
+                ctx.collective = "torch.distributed nccl all_gather_into_tensor (native sc_comm unavailable: " + "; ".join(e for e in errs if e)[:300] + ")"
+                print("bench.py: native communicator failed, using torch.distributed nccl:", errs, file=sys.stderr, flush=True)
+        else:
+            ctx.collective = f"torch.distributed {backend} on the host (rehearsal: several ranks on one device)"
 
     embed = scan = ivf = None
     with torch.cuda.stream(stream):
@@ -471,6 +524,8 @@ def main() -> None:
         "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "data": "synthetic",
     }
+    if ctx.collective:
+        line["collective"] = ctx.collective
     if embed:
         line.update({"value": embed["chunks_per_s"], "unit": "chunks/s", "ms_per_step": embed["ms_per_step"], "dtype": "bf16",
                      "config": {"workload": embed["workload"], "global_batch": args.batch * ctx.world, "seq_len": args.seq,
@@ -495,6 +550,8 @@ def main() -> None:
             else:
                 line["cpu_baseline"] = cpu_baseline_scan(args)
         print(json.dumps(line), flush=True)
+    if ctx.comm is not None:
+        ctx.comm.close()
     ctx.rt.close()
     if ctx.world > 1:
         ctx.dist.destroy_process_group()

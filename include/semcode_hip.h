@@ -279,6 +279,47 @@ sc_status sc_index_last_probe_stats(sc_index* ix, int64_t* unique_rows, int64_t*
 sc_status sc_topk_merge_host(sc_metric metric, int32_t lists, int32_t Q, int32_t k,
                              const float* dist, const int64_t* rows, float* out_dist, int64_t* out_rows);
 
+/* -------------------------------------------------------------- communicator ---- */
+
+/* The path's collectives, RCCL over xGMI, one process per GPU.  Not in the reference (a single Milvus
+ * server); this is north_star's multi-GPU scheme: the corpus is sharded by row range, every rank searches the same queries on
+ * its shard (sc_index created with row_base = shard start), ONE all-gather moves the per-shard [Q,k] results to every rank,
+ * sc_topk_merge_host merges them with the (distance, lower row id) rule.  For IVF_FLAT one rank trains, broadcasts its
+ * centroids, and every rank builds its lists for them (sc_index_assign_lists).  librccl is bound at run time on first use.
+ * All calls enqueue on the communicator's runtime stream; every rank must make the same calls in the same order. */
+typedef struct sc_comm sc_comm;
+#define SC_COMM_ID_BYTES 128
+/* Rank 0 obtains the rendezvous id (ncclGetUniqueId) and hands the 128 bytes to the other ranks out of band (an environment
+ * variable, a file, the launcher's store: control plane, not part of this library). */
+sc_status sc_comm_unique_id(void* id_out, size_t nbytes);
+/* Collective over all `world` ranks (ncclCommInitRank) on rt's device. */
+sc_status sc_comm_create(sc_runtime* rt, int32_t rank, int32_t world, const void* unique_id, size_t nbytes, sc_comm** out);
+sc_status sc_comm_destroy(sc_comm* comm);
+sc_status sc_comm_info(sc_comm* comm, int32_t* rank, int32_t* world);
+/* The search path's one exchange step: dist_dev / rows_dev [Q,k] of this rank (as written by sc_index_search_dev) ->
+ * all_dist_dev / all_rows_dev [world,Q,k] on every rank (DEVICE pointers; asynchronous on the runtime's stream; both arrays
+ * travel in one grouped RCCL launch). */
+sc_status sc_comm_allgather_topk(sc_comm* comm, const float* dist_dev, const int64_t* rows_dev, int32_t Q, int32_t k,
+                                 float* all_dist_dev, int64_t* all_rows_dev);
+/* The IVF build's one collective: nbytes at DEVICE pointer buf_dev from rank `root` to every rank (asynchronous). */
+sc_status sc_comm_broadcast(sc_comm* comm, void* buf_dev, size_t nbytes, int32_t root);
+/* Row-sharded search in one call per rank (every rank passes the same queries): this rank's shard is searched as by
+ * sc_index_search, the per-shard [Q,k] results are all-gathered and merged on the host; out_dist / out_rows [Q,k] (global row
+ * ids) are identical on every rank and equal to the result of one index over the whole corpus.  Host pointers; synchronises. */
+sc_status sc_index_search_sharded(sc_index* ix, sc_comm* comm, const float* q, int32_t Q, int32_t k, int32_t nprobe,
+                                  float* out_dist, int64_t* out_rows);
+/* The same up to the exchange, with DEVICE pointers: q_dev [Q,dim]; all_dist_dev / all_rows_dev [world,Q,k] receive every
+ * shard's result (this rank's is written in place into its own slot); enqueued on the runtime's stream like
+ * sc_index_search_dev.  The caller merges (sc_topk_merge_host) where it needs the result. */
+sc_status sc_index_search_sharded_dev(sc_index* ix, sc_comm* comm, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe,
+                                      float* all_dist_dev, int64_t* all_rows_dev);
+/* IVF_FLAT over a sharded collection: rank `root` runs sc_index_train on ITS shard, the centroids are broadcast, every other
+ * rank builds its lists for them (sc_index_assign_lists).  Probing then means the same lists on every shard. */
+sc_status sc_index_train_sharded(sc_index* ix, sc_comm* comm, int32_t niter, int32_t root);
+/* max over the ranks of a host double (in place); synchronises, so it also serves as the barrier that brackets a timed
+ * region (bench.py). */
+sc_status sc_comm_allreduce_max(sc_comm* comm, double* value);
+
 #ifdef __cplusplus
 }
 #endif

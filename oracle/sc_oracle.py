@@ -68,11 +68,30 @@ def lib() -> C.CDLL:
         h.sc_oracle_set_threads.argtypes = [C.c_int32]
         # never more OpenMP threads than CPUs this process may run on (cgroup-limited GPU boxes)
         try:
-            h.sc_oracle_set_threads(max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1)))
-        except AttributeError:  # pragma: no cover
+            h.sc_oracle_set_threads(host_cores())
+        except Exception:  # pragma: no cover
             pass
         _lib = h
     return _lib
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box gives a job a share
+    of its cores; starting one thread per visible core on a 16-core quota runs 10x slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p_ + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def pad_ld(dim: int, align: int = 64) -> int:

@@ -97,6 +97,16 @@ SIGNATURES = {
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "sc_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sc_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_comm_allgather_topk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_comm_broadcast": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
+    "sc_index_search_sharded": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_index_search_sharded_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sc_index_train_sharded": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "sc_comm_allreduce_max": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "sc_topk_merge_host": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -350,6 +360,24 @@ class Index:
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
         return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
 
+    def search_sharded(self, comm: "Comm", queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:
+        """Row-sharded search (every rank calls it with the same queries): -> the merged global (dist, rows) [Q, k]."""
+        q = _as_f32(queries, self.dim)
+        Q = q.shape[0]
+        dist = np.empty((Q, k), dtype=np.float32)
+        rows = np.empty((Q, k), dtype=np.int64)
+        _check(lib().sc_index_search_sharded(self.handle, comm.handle, q.ctypes.data_as(C.c_void_p), Q, int(k), int(nprobe),
+                                             dist.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p)))
+        return dist, rows
+
+    def search_sharded_dev(self, comm: "Comm", q_ptr: int, Q: int, k: int, all_dist_ptr: int, all_rows_ptr: int, nprobe: int = 16) -> None:
+        """Device-pointer variant: every shard's [Q, k] into all_dist / all_rows [world, Q, k] (sc_index_search_sharded_dev)."""
+        _check(lib().sc_index_search_sharded_dev(self.handle, comm.handle, C.c_void_p(q_ptr), int(Q), int(k), int(nprobe),
+                                                 C.c_void_p(all_dist_ptr), C.c_void_p(all_rows_ptr)))
+
+    def train_sharded(self, comm: "Comm", niter: int = 10, root: int = 0) -> None:
+        _check(lib().sc_index_train_sharded(self.handle, comm.handle, int(niter), int(root)))
+
     def last_probe_stats(self) -> dict:
         """After a list-major IVF probe: rows of the distinct probed lists, rows streamed, work items (sc_index_last_probe_stats)."""
         u, st, g = C.c_int64(), C.c_int64(), C.c_int32()
@@ -359,6 +387,58 @@ class Index:
     def search_dev(self, q_ptr: int, Q: int, k: int, dist_ptr: int, rows_ptr: int, nprobe: int = 16) -> None:
         """Device-pointer variant (enqueued on the runtime's stream; see sc_index_search_dev for where it synchronises)."""
         _check(lib().sc_index_search_dev(self.handle, C.c_void_p(q_ptr), int(Q), int(k), int(nprobe), C.c_void_p(dist_ptr), C.c_void_p(rows_ptr)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """The RCCL rendezvous id (rank 0 creates it and hands the 128 bytes to the other ranks out of band)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().sc_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the path's two collectives (sc_comm): the all-gather of per-shard top-k and the centroid broadcast.
+    Device pointers in, device pointers out, everything on the runtime's stream."""
+
+    def __init__(self, rt: Runtime, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        self.rt, self.rank, self.world = rt, int(rank), int(world)
+        self._h = C.c_void_p()
+        _check(lib().sc_comm_create(rt.handle, self.rank, self.world, unique_id, COMM_ID_BYTES, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().sc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("communicator is closed")
+        return self._h
+
+    def allgather_topk(self, dist_ptr: int, rows_ptr: int, Q: int, k: int, all_dist_ptr: int, all_rows_ptr: int) -> None:
+        _check(lib().sc_comm_allgather_topk(self.handle, C.c_void_p(dist_ptr), C.c_void_p(rows_ptr), int(Q), int(k),
+                                            C.c_void_p(all_dist_ptr), C.c_void_p(all_rows_ptr)))
+
+    def broadcast(self, buf_ptr: int, nbytes: int, root: int = 0) -> None:
+        _check(lib().sc_comm_broadcast(self.handle, C.c_void_p(buf_ptr), int(nbytes), int(root)))
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        _check(lib().sc_comm_allreduce_max(self.handle, C.byref(v)))
+        return v.value
 
 
 BERT_BASE = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512, type_vocab=2, ln_eps=1e-12)

@@ -23,7 +23,7 @@ LIB = OUT_DIR / "libsemcode_hip.so"
 HIP_SOURCES = sorted(p.name for p in CSRC.glob("*.hip"))
 CPP_SOURCES = sorted(p.name for p in CSRC.glob("*.cpp"))
 
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{ROOT / 'include'}"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", f"-I{ROOT / 'include'}", "-I/opt/rocm/include"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-munsafe-fp-atomics"]
 
 
@@ -78,7 +78,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     if failed:
         raise RuntimeError("hipcc failed; see messages above")
     if jobs or force or not LIB.exists():
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *map(str, objs), "-o", str(LIB)]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *map(str, objs), "-ldl", "-o", str(LIB)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stderr)

@@ -132,9 +132,18 @@ def test_store_save_load_keeps_trained_ivf_lists(rt, tmp_path):
     assert b._collection.last_search_stats()["path"] == "ivf"
     assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
     assert np.array_equal(b._collection.get_rows(0, 6000), vecs)
-    # an upsert after load invalidates the lists as usual; they are rebuilt before the next search
-    b.upsert_arrays(["k0"], vecs[1:2], ["t"], [meta])
+    # an upsert after load keeps the lists (reference: Collection.upsert into an indexed collection, milvus_store.py:128): the
+    # replaced row and a new one are assigned to the existing centroids at the next search, no k-means
+    b.upsert_arrays(["k0", "fresh"], vecs[1:3], ["t", "t"], [meta, meta])
+    assert b._needs_train is False
+    db2, rb2 = b.search_batch(vecs[1:2] + 0.01, top_k=3)
+    assert b._collection.last_search_stats()["path"] == "ivf" and set(rb2[0, :2].tolist()) == {0, 1}  # rows 0 and 1 now hold the same vector
+    assert np.array_equal(b._collection.ivf_info()["centroids"].view(np.uint32), ia["centroids"].view(np.uint32))
+    # growth to RETRAIN_GROWTH x the trained row count schedules a k-means at the next search
+    b.upsert_arrays([f"n{i}" for i in range(6000)], vecs * np.float32(1.01), ["t"] * 6000, [meta] * 6000)
     assert b._needs_train is True
+    b.search_batch(q, top_k=5)
+    assert b._needs_train is False and b._trained_rows == 12001
     a.close(); b.close()
 
 
