@@ -256,8 +256,8 @@ sc_status sc_index_assign_lists(sc_index* ix, const float* centroids, int32_t nl
 /* nlist actually trained (0 = untrained), centroids [nlist, dim] and list sizes [nlist] (either may be NULL). */
 sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* centroids, int64_t* list_sizes);
 
-/* Search path selection.  mode 0 (default): exact f32 scan for <= 16 queries, bf16-MFMA coarse scan +
- * exact f32 re-rank + certificate (uncertified queries re-run exactly) for larger batches with
+/* Search path selection.  mode 0 (default): exact f32 scan for <= 16 queries, MFMA coarse scan (int8, then bf16: see
+ * sc_index_set_coarse_stage) + exact f32 re-rank + certificate (uncertified queries re-run exactly) for larger batches with
  * k <= 64 -- both return identical results; 1: exact scan only; 2: batched path whenever supported;
  * 3: per-query IVF probing whenever the index is trained (any batch size; used to measure recall);
  * 4: list-major IVF probing (the probed lists are streamed once per group of queries that want them; same results as 3).
@@ -267,6 +267,16 @@ sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode);
 /* After a search: which path ran (1 exact, 2 batched, 3 ivf probe per query, 4 ivf probe list-major) and how many queries the batched path had to
  * re-run through the exact scan because their certificate failed. */
 sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncertified);
+
+/* Coarse stage of the batched path.  0 (default): the int8 stage first (v_mfma_i32_16x16x64_i8 at twice the bf16 rate on an int8
+ * shadow with per-row scales, 512 candidates per query); queries whose certificate fails there go to the bf16 stage (128
+ * candidates), and only what fails there too to the exact scan -- results are identical whichever stage answers.  8 / 16 pin the
+ * first stage (8: no bf16 stage in between).  An index whose int8 stage could not certify most of a batch starts at the bf16
+ * stage from then on (tightly clustered corpora); setting 0 again clears that. */
+sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits);
+/* After a batched search: the stage it started on (8 / 16) and how many queries the int8 stage handed to the bf16 stage
+ * (sc_index_last_search_stats' `uncertified` counts the queries that ended in the exact scan). */
+sc_status sc_index_last_coarse_stats(sc_index* ix, int32_t* first_stage_bits, int32_t* handed_to_bf16);
 
 /* After an IVF probe search: rows of the DISTINCT lists the batch probed (`unique_rows`: the algorithmic bytes of SURVEY.md 8d
  * config 5 = unique_rows * ld * 4), rows the scan kernel streamed (`streamed_rows`: list-major probing streams a list once per

@@ -96,6 +96,8 @@ SIGNATURES = {
     "sc_index_ivf_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "sc_index_set_search_mode": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_index_set_coarse_stage": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sc_index_last_coarse_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sc_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -355,10 +357,20 @@ class Index:
         """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (see sc_index_set_search_mode)."""
         _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3, "ivf_listmajor": 4}[mode]))
 
+    def set_coarse_stage(self, bits: int) -> None:
+        """First coarse stage of the batched path: 0 auto (int8, then bf16), 8 int8 only, 16 bf16 only (sc_index_set_coarse_stage)."""
+        _check(lib().sc_index_set_coarse_stage(self.handle, int(bits)))
+
     def last_search_stats(self) -> dict:
-        path, unc = C.c_int32(), C.c_int32()
+        """path; `uncertified` = queries that ended in the exact scan; for the batched path also the stage it started on
+        (`coarse_bits` 8 / 16) and how many queries the int8 stage handed to the bf16 stage (`handed_to_bf16`)."""
+        path, unc, bits, handed = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
-        return {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
+        _check(lib().sc_index_last_coarse_stats(self.handle, C.byref(bits), C.byref(handed)))
+        out = {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
+        if path.value == 2:
+            out.update(coarse_bits=bits.value, handed_to_bf16=handed.value)
+        return out
 
     def search_sharded(self, comm: "Comm", queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:
         """Row-sharded search (every rank calls it with the same queries): -> the merged global (dist, rows) [Q, k]."""

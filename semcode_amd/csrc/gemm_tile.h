@@ -187,11 +187,22 @@ static __device__ __forceinline__ void read_frags256(const char* At, const char*
         f.af[i] = *reinterpret_cast<const bf16x8*>(At + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
     }
 }
+// I8: the operands are int8 (16 per lane instead of 8 bf16: the same 16 bytes, so LDS image, swizzle and fragment reads are
+// byte for byte those of the bf16 tile with K counted in pairs of int8) and the accumulators hold i32 bit patterns:
+// v_mfma_i32_16x16x64_i8 takes the cycles of the bf16 form at twice the K (MI355X guide, matrix-core table).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <bool I8 = false>
 static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&acc)[4][8]) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wf[ni], f.af[mi], acc[ni][mi], 0, 0, 0);
+        for (int mi = 0; mi < 8; ++mi) {
+            if (I8)
+                acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, f.wf[ni]), __builtin_bit_cast(i32x4_t, f.af[mi]),
+                                                                                            __builtin_bit_cast(i32x4_t, acc[ni][mi]), 0, 0, 0));
+            else
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wf[ni], f.af[mi], acc[ni][mi], 0, 0, 0);
+        }
 }
 
 // acc[ni][mi][r] = sum_k A[m0 + wm*128 + mi*16 + (lane&15)][k] * W[n0 + wn*64 + ni*16 + 4*(lane>>4) + r][k]
@@ -216,7 +227,7 @@ static __device__ __forceinline__ void gemm_tile256_prologue_issue(const bf16_t*
         stage_tile256(W, ldw, n0, G_BK, smem + 3 * T_TILE_BYTES, w, lane);
     }
 }
-template <int DBG = 0, class TailHook = NoTailHook>
+template <int DBG = 0, class TailHook = NoTailHook, bool I8 = false>
 static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
                                                               int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
                                                               TailHook tail = TailHook{}, size_t a_kstep = G_BK) {
@@ -242,7 +253,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
         char* cur = smem + (kt & 1) * (2 * T_TILE_BYTES);
         char* nxt = smem + ((kt + 1) & 1) * (2 * T_TILE_BYTES);
         if (!(DBG & 4)) read_frags256(cur, cur + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
-        if (!(DBG & 2)) mfma_frags256(f0, acc);
+        if (!(DBG & 2)) mfma_frags256<I8>(f0, acc);
         else asm volatile("" ::"v"(f0.wf[0]), "v"(f0.af[0]), "v"(f0.wf[3]), "v"(f0.af[7]));
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my LDS-DMA of tile kt+1 (issued one K-tile ago)
@@ -253,7 +264,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
             stage_tile256(W, ldw, n0, (kt + 2) * G_BK, cur + T_TILE_BYTES, w, lane);
         }
         if (NEXT && !(DBG & 4)) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
-        if (!(DBG & 2)) mfma_frags256(f1, acc);
+        if (!(DBG & 2)) mfma_frags256<I8>(f1, acc);
         else asm volatile("" ::"v"(f1.wf[0]), "v"(f1.af[0]), "v"(f1.wf[3]), "v"(f1.af[7]));
         if (STAGE && !(DBG & 1) && NEXT && !(DBG & 2) && !(DBG & 4)) {
             // spread the 8 LDS-DMA issues (each ~100 issue cycles with its address arithmetic) and the 12 fragment reads

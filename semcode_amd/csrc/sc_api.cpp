@@ -227,8 +227,12 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->io);
     hipFree(ix->Xb);
     hipFree(ix->xnorm_max);
+    hipFree(ix->Xq);
+    hipFree(ix->xscale);
+    hipFree(ix->xnorm_max8);
     hipFree(ix->bscratch);
     hipFree(ix->fb);
+    hipFree(ix->fb2);
     hipFree(ix->perm);
     hipFree(ix->list_off);
     hipFree(ix->ivf_scratch);
@@ -390,7 +394,8 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
     }
     ix->n = next;
     if (!ix->perm) ix->trained = false;
-    if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the bf16 shadow; appended rows get theirs lazily
+    if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the shadows; appended rows get theirs lazily
+    if (min_old < ix->shadow8_rows) ix->shadow8_rows = 0;
     return SC_OK;
 }
 
@@ -457,6 +462,8 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     ix->n = n;
     ix->trained = false;
     ix->shadow_rows = 0;
+    ix->shadow8_rows = 0;
+    ix->i8_off = false;
     return SC_OK;
 }
 
@@ -475,6 +482,8 @@ extern "C" sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, 
     ix->n = n;
     ix->trained = false;
     ix->shadow_rows = 0;
+    ix->shadow8_rows = 0;
+    ix->i8_off = false;
     return SC_OK;
 }
 
@@ -485,10 +494,13 @@ extern "C" sc_status sc_index_release_scratch(sc_index* ix) {
     SC_HIP(hipSetDevice(ix->rt->device));
     SC_HIP(hipStreamSynchronize(ix->rt->stream));
     hipFree(ix->Xb); ix->Xb = nullptr; ix->xb_cap = 0; ix->shadow_rows = 0;
+    hipFree(ix->Xq); ix->Xq = nullptr; ix->xq_cap = 0; ix->shadow8_rows = 0;
+    hipFree(ix->xscale); ix->xscale = nullptr; ix->xscale_cap = 0;
     hipFree(ix->bscratch); ix->bscratch = nullptr; ix->bscratch_cap = 0;
     hipFree(ix->partial); ix->partial = nullptr; ix->partial_cap = 0;
     hipFree(ix->stage); ix->stage = nullptr; ix->stage_cap = 0;
     hipFree(ix->fb); ix->fb = nullptr; ix->fb_cap = 0;
+    hipFree(ix->fb2); ix->fb2 = nullptr; ix->fb2_cap = 0;
     hipFree(ix->ivf_scratch); ix->ivf_scratch = nullptr; ix->ivf_scratch_cap = 0;
     return SC_OK;
 }
@@ -565,6 +577,48 @@ static sc_status ensure_shadow(sc_index* ix) {
     return SC_OK;
 }
 
+static inline int ld8_of(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }  // int8 row stride: whole 128-byte K-tiles
+
+static sc_status ensure_shadow8(sc_index* ix) {
+    hipStream_t s = ix->rt->stream;
+    const int64_t rows_pad = (ix->n + 255) / 256 * 256;
+    const int ld8 = ld8_of(ix);
+    const size_t need = (size_t)rows_pad * ld8;
+    if (need > ix->xq_cap || (size_t)rows_pad * 4 > ix->xscale_cap) {
+        SC_HIP(hipStreamSynchronize(s));
+        hipFree(ix->Xq);
+        hipFree(ix->xscale);
+        ix->Xq = nullptr;
+        ix->xscale = nullptr;
+        ix->xq_cap = ix->xscale_cap = 0;
+        ix->shadow8_rows = 0;
+        const size_t cap_rows = (size_t)((std::max(ix->capacity, ix->n) + 255) / 256 * 256);
+        hipError_t e = hipMalloc(&ix->Xq, cap_rows * ld8);
+        if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc int8 shadow (%zu B) failed: %s", cap_rows * ld8, hipGetErrorString(e));
+        ix->xq_cap = cap_rows * ld8;
+        e = hipMalloc((void**)&ix->xscale, cap_rows * 4);
+        if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc int8 scales failed: %s", hipGetErrorString(e));
+        ix->xscale_cap = cap_rows * 4;
+    }
+    if (!ix->xnorm_max8) {
+        hipError_t e = hipMalloc((void**)&ix->xnorm_max8, 16);
+        if (e != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+        ix->shadow8_rows = 0;
+    }
+    if (ix->shadow8_rows < ix->n) {
+        if (ix->shadow8_rows == 0) SC_HIP(hipMemsetAsync(ix->xnorm_max8, 0, 16, s));
+        sc_launch_shadow8(ix->X, ix->xnorm, ix->shadow8_rows, ix->n - ix->shadow8_rows, ix->ld, ld8, ix->Xq, ix->xscale, ix->xnorm_max8 + 1, s);
+        if (rows_pad > ix->n) {  // the last row tile reads these rows
+            SC_HIP(hipMemsetAsync((char*)ix->Xq + (size_t)ix->n * ld8, 0, (size_t)(rows_pad - ix->n) * ld8, s));
+            SC_HIP(hipMemsetAsync(ix->xscale + ix->n, 0, (size_t)(rows_pad - ix->n) * 4, s));
+        }
+        sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max8, s);
+        ix->shadow8_rows = ix->n;
+        SC_HIP(hipGetLastError());
+    }
+    return SC_OK;
+}
+
 static const int BATCH_CAP = 4096;        // survivors kept per query and phase
 static const int64_t PHASE0_ROWS = 256;   // first phase (every row of it survives, and selection is quadratic in the survivors); each next phase covers 4x more rows
 
@@ -575,12 +629,27 @@ static bool batched_applicable(const sc_index* ix, int Q, int k) {
     return Q > 16 && ix->n >= 4096;
 }
 
-static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
+// The int8 stage is tried first (twice the MFMA rate, half the shadow bytes); what it cannot certify goes to the bf16 stage, and
+// only what that cannot certify either to the exact scan.  SC_COARSE=bf16 | i8 pins the stage (A/B runs, tests).
+static int coarse_env();
+static int coarse_pin(const sc_index* ix) { return ix->coarse_mode ? ix->coarse_mode : coarse_env(); }
+static int coarse_env() {
+    static const int v = [] {
+        const char* e = getenv("SC_COARSE");
+        if (!e) return 0;
+        return (e[0] == 'b' || e[0] == 'B') ? 16 : (e[0] == 'i' || e[0] == 'I') ? 8 : 0;
+    }();
+    return v;
+}
+
+static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows, bool i8, int depth,
+                                             int Q_top) {
     sc_runtime* rt = ix->rt;
     hipStream_t s = rt->stream;
-    const int metric = (int)ix->metric, ld = ix->ld, KP = sc_batched_kprime();
-    const int Qpad = Q > 128 ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches
-    sc_status st = ensure_shadow(ix);
+    const int metric = (int)ix->metric, ld = ix->ld, KP = i8 ? sc_batched_kprime8() : sc_batched_kprime();
+    const int ld8 = ld8_of(ix);
+    const int Qpad = (i8 || Q > 128) ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches (always for the int8 stage)
+    sc_status st = i8 ? ensure_shadow8(ix) : ensure_shadow(ix);
     if (st) return st;
     st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
     if (st) return st;
@@ -590,58 +659,74 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_qres = carve((size_t)Q * 4);
-    const size_t o_qb = carve((size_t)Qpad * ld * 2), o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4),
-                 o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8),
-                 o_surv = carve((size_t)Q * BATCH_CAP * 8);
+    const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
+                 o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
+                 o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8);
+    // the fallback sub-batch (depth 1) runs while the caller's scratch is no longer needed: one buffer serves both
     st = sc_grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
     if (st) return st;
     char* b = (char*)ix->bscratch;
     void* Qb = b + o_qb;
     float* qres = (float*)(b + o_qres);
-    float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
+    float *qscale = (float*)(b + o_qs), *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
     unsigned* cnt = (unsigned*)(b + o_cnt);
     int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
-    uint64_t *best = (uint64_t*)(b + o_best), *surv = (uint64_t*)(b + o_surv);
+    uint64_t *best = (uint64_t*)(b + o_best), *ekeys = (uint64_t*)(b + o_ek), *surv = (uint64_t*)(b + o_surv);
 
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
-    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, s);
+    if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, s);
+    else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
+    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
     int64_t r0 = 0, span = PHASE0_ROWS;
     while (r0 < ix->n) {
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-        sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s);
+        if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, r0, r1, ld8, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale);
+        else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-        sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, s);
+        sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
         sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
         r0 = r1;
         span *= 4;
     }
-    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->xnorm_max, qres, ovf, Q, k, ix->row_base, ix->perm,
-                          out_dist, out_rows, flags, s);
+    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, i8 ? ix->xnorm_max8 : ix->xnorm_max, qres, ovf, Q, k, ix->row_base,
+                          ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
     SC_HIP(hipGetLastError());
-    // uncertified queries (rare): redo them with the exact scan
+    // uncertified queries: hand them to the next stage (int8 -> bf16 -> exact scan)
     std::vector<int> hflags(Q);
     SC_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)Q * 4, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
     std::vector<int> redo;
     for (int i = 0; i < Q; ++i)
         if (hflags[i]) redo.push_back(i);
-    ix->last_uncertified = (int)redo.size();
-    ix->uncert_frac = (double)redo.size() / (double)Q;
-    if (!redo.empty()) {
-        const int R = (int)redo.size();
+    const int R = (int)redo.size();
+    const bool to_bf16 = i8 && coarse_pin(ix) != 8 && R > 16;  // a handful of queries is one pass of the exact scan: not worth a bf16 shadow
+    if (i8) {
+        ix->last_uncert_i8 = R;
+        // most of a real batch uncertified: this corpus does not quantise well enough (tight clusters, outlier dimensions) --
+        // later searches start at the bf16 stage until the rows are replaced wholesale
+        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8) ix->i8_off = true;
+    }
+    if (!to_bf16) {  // what is left goes to the exact scan
+        ix->last_uncertified = R;
+        ix->uncert_frac = (double)R / (double)Q_top;
+    }
+    if (R > 0) {
+        // the sub-batch gets its own staging (queries + results); nested stages each need one: fb for the first, fb2 for the second
+        void** buf = depth == 0 ? &ix->fb : &ix->fb2;
+        size_t* cap = depth == 0 ? &ix->fb_cap : &ix->fb2_cap;
         const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
-        st = sc_grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
+        st = sc_grow(ix, buf, cap, qb + db + (size_t)R * k * 8);
         if (st) return st;
-        float* fq = (float*)ix->fb;
-        float* fd = (float*)((char*)ix->fb + qb);
-        int64_t* fr = (int64_t*)((char*)ix->fb + qb + db);
+        float* fq = (float*)*buf;
+        float* fd = (float*)((char*)*buf + qb);
+        int64_t* fr = (int64_t*)((char*)*buf + qb + db);
         for (int j = 0; j < R; ++j)
             SC_HIP(hipMemcpyAsync(fq + (size_t)j * ix->dim, q_dev + (size_t)redo[j] * ix->dim, (size_t)ix->dim * 4, hipMemcpyDeviceToDevice, s));
-        st = search_exact_locked(ix, fq, R, k, 0, fd, fr);
+        if (to_bf16) st = search_batched_stage_locked(ix, fq, R, k, fd, fr, false, depth + 1, Q_top);
+        else st = search_exact_locked(ix, fq, R, k, 0, fd, fr);
         if (st) return st;
         for (int j = 0; j < R; ++j) {
             SC_HIP(hipMemcpyAsync(out_dist + (size_t)redo[j] * k, fd + (size_t)j * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
@@ -650,6 +735,15 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     }
     ix->last_path = 2;
     return SC_OK;
+}
+
+static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
+    const int env = coarse_pin(ix);
+    const bool i8 = env == 8 || (env == 0 && !ix->i8_off);
+    ix->last_coarse_bits = i8 ? 8 : 16;
+    ix->last_uncert_i8 = 0;
+    ix->last_uncertified = 0;
+    return search_batched_stage_locked(ix, q_dev, Q, k, out_dist, out_rows, i8, 0, Q);
 }
 
 sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
@@ -690,6 +784,22 @@ extern "C" sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int
     std::lock_guard<std::mutex> g(ix->mu);
     if (path) *path = ix->last_path;
     if (uncertified) *uncertified = ix->last_uncertified;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits) {
+    if (!ix || (bits != 0 && bits != 8 && bits != 16)) return sc_fail(SC_ERR_INVALID, "sc_index_set_coarse_stage: bits must be 0 (auto), 8 or 16");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->coarse_mode = bits;
+    if (bits == 0) ix->i8_off = false;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_coarse_stats(sc_index* ix, int32_t* first_stage_bits, int32_t* handed_to_bf16) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (first_stage_bits) *first_stage_bits = ix->last_coarse_bits;
+    if (handed_to_bf16) *handed_to_bf16 = ix->last_uncert_i8;
     return SC_OK;
 }
 

@@ -102,20 +102,25 @@ bool sc_topk_gather_merge_supported(int lists_per_query, int k);
 void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int32_t* src, int lists_per_query, int Q, int k,
                                  int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
 
-// scan_batched.hip: bf16 shadow, coarse GEMM + filter phases, selection, exact re-rank
-int sc_batched_kprime(void);
+// scan_batched.hip: bf16 / int8 shadows, coarse GEMM + filter phases, selection, exact re-rank
+int sc_batched_kprime(void);   // candidates kept per query: bf16 stage
+int sc_batched_kprime8(void);  // int8 stage
 void sc_launch_shadow(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, void* Xb, unsigned* res_bits, hipStream_t s);
+void sc_launch_shadow8(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, int ld8, void* Xq, float* xscale, unsigned* res_bits,
+                       hipStream_t s);
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s);
 void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s);
-void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, hipStream_t s);
+void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, hipStream_t s);
+void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, int kp, hipStream_t s);
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
-                           int cap, hipStream_t s);
+                           int cap, hipStream_t s, bool i8 = false, const float* xscale = nullptr, const float* qscale = nullptr);
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
-                           float* thr_fast, int* overflow, int Q, hipStream_t s);
+                           float* thr_fast, int* overflow, int Q, int kp, hipStream_t s);
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
                            const float* thr, const unsigned* xnorm_max_bits, const float* qres, const int* overflow, int Q, int k,
-                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s);
+                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s,
+                           int kp, uint64_t* ekeys);
 
 // ivf.hip
 void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,

@@ -64,8 +64,18 @@ struct sc_index {
     void* Xb = nullptr;      size_t xb_cap = 0;   // bytes
     int64_t shadow_rows = 0;                      // rows [0, shadow_rows) of Xb are valid
     unsigned* xnorm_max = nullptr;                // device: bits of max |x|^2
+    // int8 coarse stage: int8 shadow (rows of ld8 = ld rounded up to 128 bytes, rows padded to 256) + per-row scale
+    void* Xq = nullptr;      size_t xq_cap = 0;   // bytes
+    float* xscale = nullptr; size_t xscale_cap = 0;
+    int64_t shadow8_rows = 0;
+    unsigned* xnorm_max8 = nullptr;               // device: bits of {max |x|^2, max |x - s q|^2, max relative}
+    int coarse_mode = 0;                          // sc_index_set_coarse_stage: 0 auto (int8 first), 8 int8 only, 16 bf16 only
+    bool i8_off = false;                          // the int8 certificate failed for most of a batch on this corpus: use the bf16 stage
+    int last_coarse_bits = 0;                     // 8 / 16: coarse stage of the last batched search
+    int last_uncert_i8 = 0;                       // queries the int8 stage handed on to the bf16 stage
     void* bscratch = nullptr; size_t bscratch_cap = 0;
-    void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results)
+    void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results) of the first stage's uncertified queries
+    void* fb2 = nullptr;     size_t fb2_cap = 0;  // the same for the second stage (int8 -> bf16 -> exact)
     // IVF_FLAT (after sc_index_train): X / xnorm are stored list-major
     sc_index* quant = nullptr;                    // flat index over the nlist centroids (coarse quantizer)
     uint32_t* perm = nullptr;                     // device [ivf_rows]: stored position -> row id (insertion order)

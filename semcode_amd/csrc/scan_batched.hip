@@ -26,7 +26,20 @@
 #include "gemm_tile.h"
 
 #define KPRIME 128         // coarse candidates kept per query (one re-rank thread each)
+#define KPRIME8 512        // the same for the int8 coarse stage, whose error bound is ~7x wider (see below)
 #define SEL_THREADS 256
+
+// ---- int8 coarse stage -------------------------------------------------------------------------------------------------
+// At Q = 1024 the bf16 GEMM is the whole cost (15 ms at 1.0 PF; 6.3 ms even at the nominal peak).  v_mfma_i32_16x16x64_i8 runs
+// at twice the bf16 rate, so the coarse scores can also be taken from an int8 shadow: row r is stored as q_r = round(x_r / s_r),
+// s_r = max|x_r| / 127 (7.7 GB at 10M x 768), the query likewise, and <x,q> ~ s_r s_q <q_r,q_q> with an EXACT integer dot.
+// Nothing else changes: survivors below a per-query threshold, the KPRIME8 best kept between phases, every candidate re-scored in
+// f32 in the canonical order (returned distances stay bit-identical to the exact path), and the same certificate
+//     kth exact score + eps_q < tau_q      with eps_q from Cauchy-Schwarz on the ACTUAL rounding residuals
+//     |<x,q> - s_r s_q <q_r,q_q>| <= max_r|x_r - s_r q_r| |q| + max_r|s_r q_r| |q - s_q q_q| .
+// int8 residuals are ~7x those of bf16 (step max|x|/127 vs 2^-9 relative), so tau_q has to sit further out: 512 candidates
+// instead of 128 (on N(0,1) data at 768 dimensions eps ~ 24 in squared-L2 units against a gap of ~48 between the 10th and the
+// 512th neighbour).  A query that fails the int8 certificate is re-run on the bf16 stage, and only then exactly.
 
 // ------------------------------------------------------------------ bf16 shadow + max norm + max rounding residual
 // One wave per row: Xb = bf16(X); res_bits = max over rows of |x - bf16(x)|^2 (the certificate's error bound uses the
@@ -95,6 +108,68 @@ __global__ __launch_bounds__(256) void query_bf16_kernel(const float* __restrict
     if (lane == 0 && q < Q) qres[q] = res * 1.0001f;
 }
 
+// int8 shadow: one wave per row.  Xq [rows][ld8] int8 (ld8 = ld rounded up to 128, zero padded), xscale[row] = s_r,
+// res_bits[1] / [2] = max |x - s q|^2 and max |x - s q|^2 / |x|^2 over the rows (the certificate's bound).
+template <bool QUERY>
+__global__ __launch_bounds__(256) void shadow8_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int64_t first, int64_t n, int64_t nout,
+                                                       int ld, int ld8, int8_t* __restrict__ Xq, float* __restrict__ xscale,
+                                                       unsigned* __restrict__ res_bits, float* __restrict__ qres) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float worst = 0.f, worst_rel = 0.f;
+    for (int64_t r = wave0; r < nout; r += nwaves) {  // QUERY: rows n .. nout are padding (zeros, scale 1)
+        const bool real = r < n;
+        const float* x = X + (first + r) * (int64_t)ld;
+        float m = 0.f;
+        if (real)
+            for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const float sc = m > 0.f ? m * (1.0f / 127.0f) : 1.0f;
+        const float inv = 1.0f / sc;
+        float res = 0.f;
+        int8_t* o = Xq + (first + r) * (int64_t)ld8;
+        for (int k0 = 16 * lane; k0 < ld8; k0 += 1024) {
+            u32x4 packed = {0u, 0u, 0u, 0u};
+            if (real && k0 < ld) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j);
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float qf = fminf(fmaxf(rintf(v[c] * inv), -127.0f), 127.0f);
+                        const float d = fmaf(-sc, qf, v[c]);
+                        res = fmaf(d, d, res);
+                        word |= ((uint32_t)(int)qf & 0xFFu) << (8 * c);
+                    }
+                    packed[j] = word;
+                }
+            }
+            *reinterpret_cast<u32x4*>(o + k0) = packed;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+        if (lane == 0) xscale[first + r] = sc;
+        if (QUERY) {
+            if (lane == 0 && real) qres[r] = res * 1.0001f;
+        } else {
+            worst = fmaxf(worst, res);
+            const float xn = xnorm[first + r];
+            if (xn > 0.f) worst_rel = fmaxf(worst_rel, res / xn);
+        }
+    }
+    if (!QUERY && lane == 0 && worst > 0.f) {
+        atomicMax(res_bits, __builtin_bit_cast(unsigned, worst * 1.0001f));
+        atomicMax(res_bits + 1, __builtin_bit_cast(unsigned, worst_rel * 1.0001f));
+    }
+}
+
 // ------------------------------------------------------------------ coarse GEMM + filter
 struct CoarseArgs {
     const bf16_t* Xb;      // [rows padded to 128, ld]
@@ -110,6 +185,8 @@ struct CoarseArgs {
     unsigned* count;       // [Q]
     int cap;
     int ntiles;
+    const float* xscale;   // int8 stage: s_r per corpus row (rows padded to 256 hold anything finite)
+    const float* qscale;   // int8 stage: s_q per query [Qpad]
 };
 
 template <int METRIC>
@@ -175,20 +252,24 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 // Per-query thresholds / norms of the workgroup's 256 queries sit in LDS behind the pipeline buffers, and a
 // lane queues its (rare) hits in registers so that the global atomics that allocate list slots are issued
 // back to back and their latency is paid once per tile, not once per hit.
-#define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256]} in LDS
+#define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256], qscale[256], xscale[256]} in LDS
+#define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 6 * 256 * 4)
 // per-tile staging of the workgroup's 256 query thresholds / norms and the tile's 256 row norms (visible to everyone after
 // the main loop's barriers)
+template <bool I8 = false>
 static __device__ __forceinline__ void coarse256_stage(const CoarseArgs& a, int64_t m0, int n0, char* smem, int tid) {
     float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
     if (tid >= 256) {
         const int64_t row = m0 + (tid - 256);
         q_tf[768 + tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
+        if (I8) q_tf[1280 + tid - 256] = row < a.row1 ? a.xscale[row] : 0.0f;
     }
     if (tid < 256) {
         const int q = n0 + tid;
         q_tf[tid] = a.thr_fast[q];  // padded to Qpad and +inf-initialised
         q_tf[256 + tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
         q_tf[512 + tid] = q < a.Q ? a.qnorm[q] : 1.0f;
+        if (I8) q_tf[1024 + tid] = a.qscale[q];  // padded to Qpad
     }
 }
 // tile (rt, qt) of logical tile index `tile`: column-major walk inside groups of 8 row panels (as the encoder GEMMs once did)
@@ -199,7 +280,7 @@ static __device__ __forceinline__ void coarse256_coords(const CoarseArgs& a, int
     m0 = a.row0 + (int64_t)(g * G + r % rows_here) * T_BM;
     n0 = (r / rows_here) * T_BN;
 }
-template <int METRIC>
+template <int METRIC, bool I8 = false>
 static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
                                                           int lane) {
     const int wm = w >> 2, wn = w & 3;
@@ -210,9 +291,12 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     const float* x_xn = q_tf + 768;  // |x|^2 of the tile's 256 corpus rows
     // acc[ni][mi][r] = <x[m0 + wm*128 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
     const int fr = lane & 15, fq = lane >> 4;
-    f32x4 tf[4];
+    f32x4 tf[4], sq[4];  // sq: int8 stage only, the query scales of this lane's 16 columns
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) tf[ni] = *reinterpret_cast<const f32x4*>(q_tf + wn * 64 + ni * 16 + 4 * fq);
+    for (int ni = 0; ni < 4; ++ni) {
+        tf[ni] = *reinterpret_cast<const f32x4*>(q_tf + wn * 64 + ni * 16 + 4 * fq);
+        if (I8) sq[ni] = *reinterpret_cast<const f32x4*>(q_tf + 1024 + wn * 64 + ni * 16 + 4 * fq);
+    }
     // hits of this lane: up to 4 queued (local query index, key); a 5th and later ones are flushed directly
     int nh = 0;
     int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
@@ -222,16 +306,23 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         const int rl = wm * 128 + mi * 16 + fr;
         const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
+        const float sx = I8 ? q_tf[1280 + rl] : 0.f;  // int8 stage: the integer dot is scaled by s_r s_q
+        const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dot = acc[ni][mi][r];
-                if (METRIC == SC_METRIC_L2) t[r] = fmaf(-2.0f, dot, xn);
-                else if (METRIC == SC_METRIC_COSINE) t[r] = -dot * xs;
-                else t[r] = -dot;
+                if (I8) {
+                    const float av = (float)__builtin_bit_cast(int, acc[ni][mi][r]) * ar;
+                    t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
+                } else {
+                    const float dot = acc[ni][mi][r];
+                    if (METRIC == SC_METRIC_L2) t[r] = fmaf(-2.0f, dot, xn);
+                    else if (METRIC == SC_METRIC_COSINE) t[r] = -dot * xs;
+                    else t[r] = -dot;
+                }
             }
             const bool g = (t[0] <= tf[ni][0]) | (t[1] <= tf[ni][1]) | (t[2] <= tf[ni][2]) | (t[3] <= tf[ni][3]);
             if (__any(g)) {
@@ -240,7 +331,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
                 for (int r = 0; r < 4; ++r) {
                     if (row < a.row1 && t[r] <= tf[ni][r]) {
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
-                        const float sc = sc_score<METRIC>(acc[ni][mi][r], xn, q_qn[ql]);
+                        const float dotv = I8 ? (float)__builtin_bit_cast(int, acc[ni][mi][r]) * (sx * sq[ni][r]) : acc[ni][mi][r];
+                        const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries
                             const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
@@ -272,7 +364,7 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
 
-template <int METRIC, int DBG = 0>
+template <int METRIC, int DBG = 0, bool I8 = false>
 __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -280,13 +372,14 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     int64_t m0;
     int n0;
     coarse256_coords(a, xcd_remap(blockIdx.x, a.ntiles), m0, n0);
-    coarse256_stage(a, m0, n0, smem, tid);
+    coarse256_stage<I8>(a, m0, n0, smem, tid);
     f32x4 acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_tile256_mainloop<0>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+    // int8 stage: a.ld counts PAIRS of int8 (the tile machinery addresses 2-byte elements), zero accumulators are zero i32 bits
+    gemm_tile256_mainloop<0, NoTailHook, I8>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
     asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
     __builtin_amdgcn_sched_barrier(0);
     if (DBG) {  // diagnostic: main loop only
@@ -298,33 +391,33 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
         if (sink == 12345.678f) a.count[0] = 1;
         return;
     }
-    coarse256_epilogue<METRIC>(a, acc, m0, n0, smem, w, lane);
+    coarse256_epilogue<METRIC, I8>(a, acc, m0, n0, smem, w, lane);
 }
 
 // A persistent variant (one workgroup per CU walking tiles b, b + grid, ..., the tail hook of tile t requesting K-tiles 0 and 1 of
 // tile t + grid under its last 32 MFMAs) was built and measured in a same-box A/B: 64.7k -> 60.4k QPS.  Like both persistent walks
 // tried on the encoder GEMMs it loses to hardware dispatch of one workgroup per tile; DESIGN.md section 8.
 
-// ------------------------------------------------------------------ per-phase selection: keep the KPRIME best coarse keys
-// best [Q][KPRIME] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
+// ------------------------------------------------------------------ per-phase selection: keep the kp (KPRIME or KPRIME8) best coarse keys
+// best [Q][kp] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
 template <int METRIC>
 __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __restrict__ surv, unsigned* __restrict__ count, int cap,
                                                                    uint64_t* __restrict__ best, const float* __restrict__ qnorm,
                                                                    float* __restrict__ thr, float* __restrict__ thr_fast,
-                                                                   int* __restrict__ overflow) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + KPRIME] candidates, [KPRIME] output
+                                                                   int* __restrict__ overflow, int kp) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + kp] candidates, [kp] output
     uint64_t* cand = sel_lds;
-    uint64_t* outk = sel_lds + cap + KPRIME;
+    uint64_t* outk = sel_lds + cap + kp;
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned c = count[q];
     if (c > (unsigned)cap) {
         if (tid == 0) overflow[q] = 1;
         c = cap;
     }
-    const int n = (int)c + KPRIME;
+    const int n = (int)c + kp;
     for (int i = tid; i < (int)c; i += SEL_THREADS) cand[i] = surv[(size_t)q * cap + i];
-    for (int i = tid; i < KPRIME; i += SEL_THREADS) {
-        cand[c + i] = best[(size_t)q * KPRIME + i];
+    for (int i = tid; i < kp; i += SEL_THREADS) {
+        cand[c + i] = best[(size_t)q * kp + i];
         outk[i] = SC_KEY_MAX;
     }
     __syncthreads();
@@ -334,13 +427,13 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
         if (key == SC_KEY_MAX) continue;
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += (cand[j] < key) ? 1 : 0;
-        if (rank < KPRIME) outk[rank] = key;
+        if (rank < kp) outk[rank] = key;
     }
     __syncthreads();
-    for (int i = tid; i < KPRIME; i += SEL_THREADS) best[(size_t)q * KPRIME + i] = outk[i];
+    for (int i = tid; i < kp; i += SEL_THREADS) best[(size_t)q * kp + i] = outk[i];
     if (tid == 0) {
         count[q] = 0;
-        const uint64_t kth = outk[KPRIME - 1];
+        const uint64_t kth = outk[kp - 1];
         float t = __builtin_inff(), tf = __builtin_inff();
         if (kth != SC_KEY_MAX) {
             const float sc = sc_key_score(METRIC, kth);
@@ -364,21 +457,48 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
 // the chain conflict-free), the next tile's loads in flight while this one is multiplied.  The chain itself is unchanged:
 // k = 16 t + 4 g + c, c outer, g inner -- bit-identical scores.
 #define RR_STRIDE 68  // floats per LDS row
+
+// The certificate: is the k-th exact key provably better than every row that is NOT a candidate?  Such a row has coarse
+// v-score >= tau, hence exact v-score >= tau - eps with
+//   |coarse dot - exact dot| <= |x - xc| |q| + |xc| |q - qc| + accumulation noise   (Cauchy-Schwarz on the ACTUAL rounding
+// residuals of the coarse operands xc, qc -- bf16 or scaled int8; bits = {max |x|^2, max |x - xc|^2, max |x - xc|^2 / |x|^2}
+// over the corpus, qres = |q - qc|^2).  The int8 dot itself is exact; its scaling to f32 rounds three times, which the
+// ld * 1.2e-7 term (sized for the f32 accumulation of the bf16 stage) covers many times over.
 template <int METRIC>
+static __device__ __forceinline__ bool certified(uint64_t kth_key, const unsigned* __restrict__ bits, float qnorm2, float qres2, int ld, float tau) {
+    const float xmax = sqrtf(__builtin_bit_cast(float, bits[0]));
+    const float xres = sqrtf(__builtin_bit_cast(float, bits[1]));
+    const float qn = sqrtf(qnorm2);
+    const float ddot = xres * qn + (xmax + xres) * sqrtf(qres2) + (float)ld * 1.2e-7f * (xmax + xres) * qn;
+    float eps;
+    if (METRIC == SC_METRIC_L2) eps = 2.0f * ddot;
+    else if (METRIC == SC_METRIC_COSINE) {  // relative form: |x - xc|/|x| + (1 + .)|q - qc|/|q|
+        const float relx = sqrtf(__builtin_bit_cast(float, bits[2]));
+        eps = relx + (1.0f + relx) * (sqrtf(qres2) / fmaxf(qn, 1e-30f)) + (float)ld * 1.2e-7f * (1.0f + relx);
+    } else eps = ddot;
+    eps = eps * 1.01f + 1e-6f;
+    const float sc = sc_key_score(METRIC, kth_key);
+    const float vk = (METRIC == SC_METRIC_L2) ? sc : -sc;
+    return vk + eps < tau;
+}
+// SPLIT (int8 stage, KPRIME8 candidates): blockIdx.y selects a block of 128 candidates, the exact keys go to ekeys [Q][kp] and
+// scan_finalize_kernel sorts them and evaluates the certificate.
+template <int METRIC, bool SPLIT = false>
 __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int ld,
                                                           const float* __restrict__ Qp, const float* __restrict__ qnorm,
                                                           const uint64_t* __restrict__ best, const float* __restrict__ thr,
                                                           const unsigned* __restrict__ xnorm_max_bits, const float* __restrict__ qres,
                                                           const int* __restrict__ overflow, int k,
                                                           int64_t row_base, const uint32_t* __restrict__ perm, float* __restrict__ out_dist,
-                                                          int64_t* __restrict__ out_rows, int* __restrict__ flags) {
+                                                          int64_t* __restrict__ out_rows, int* __restrict__ flags, int kp = KPRIME,
+                                                          uint64_t* __restrict__ ekeys = nullptr) {
     static_assert(KPRIME == 128, "the cooperative tile load assumes 128 candidates = 128 threads");
     __shared__ uint64_t keys[KPRIME];
     __shared__ uint32_t rowid[KPRIME];
     __shared__ __attribute__((aligned(16))) float tile[KPRIME * RR_STRIDE];
     __shared__ __attribute__((aligned(16))) float qch[64];
     const int q = blockIdx.x, lane = threadIdx.x;
-    const uint64_t ck = best[(size_t)q * KPRIME + lane];
+    const uint64_t ck = best[(size_t)q * kp + (SPLIT ? blockIdx.y * KPRIME : 0) + lane];
     rowid[lane] = ck != SC_KEY_MAX ? (uint32_t)ck : 0u;  // padding slots re-score row 0 and are discarded below
     __syncthreads();
     const int seg = lane & 15, r0 = lane >> 4;  // this thread fetches 16-byte piece `seg` of rows r0, r0 + 8, ...
@@ -420,6 +540,10 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
         const uint32_t row = (uint32_t)ck;
         ek = sc_make_key<METRIC>(sc_score<METRIC>(acc, xnorm[row], qnorm[q]), perm ? perm[row] : row);  // ties: reported row id
     }
+    if (SPLIT) {
+        ekeys[(size_t)q * kp + blockIdx.y * KPRIME + lane] = ek;
+        return;
+    }
     keys[lane] = ek;
     __syncthreads();
     int rank = 0;
@@ -445,47 +569,86 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
     if (lane == 0) {
         int bad = overflow[q];
         if (have == KPRIME) {  // otherwise every row of the corpus is a candidate: nothing can be missing
-            // |coarse dot - exact dot| <= |x - xb| |q| + |xb| |q - qb| + f32 accumulation noise  (Cauchy-Schwarz on the
-            // actual rounding residuals; xnorm_max_bits = {max |x|^2, max |x - xb|^2} over the corpus)
-            const float xmax = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[0]));
-            const float xres = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[1]));
-            const float qn = sqrtf(qnorm[q]);
-            const float ddot = xres * qn + (xmax + xres) * sqrtf(qres[q]) + (float)ld * 1.2e-7f * (xmax + xres) * qn;
-            float eps;
-            if (METRIC == SC_METRIC_L2) eps = 2.0f * ddot;
-            else if (METRIC == SC_METRIC_COSINE) {  // relative form: |x - xb|/|x| + (1 + .)|q - qb|/|q|
-                const float relx = sqrtf(__builtin_bit_cast(float, xnorm_max_bits[2]));
-                eps = relx + (1.0f + relx) * (sqrtf(qres[q]) / fmaxf(qn, 1e-30f)) + (float)ld * 1.2e-7f * (1.0f + relx);
-            }
-            else eps = ddot;
-            eps = eps * 1.01f + 1e-6f;
             const int kk = k < have ? k : have;
-            const float sc = sc_key_score(METRIC, keys[kk - 1]);
-            const float vk = (METRIC == SC_METRIC_L2) ? sc : -sc;
-            if (!(vk + eps < thr[q])) bad = 1;
+            if (!certified<METRIC>(keys[kk - 1], xnorm_max_bits, qnorm[q], qres[q], ld, thr[q])) bad = 1;
+        }
+        flags[q] = bad;
+    }
+}
+
+// int8 stage: the KPRIME8 exact keys of one query (scan_rerank_kernel<.., SPLIT>) -> sorted top-k + certificate
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_finalize_kernel(const uint64_t* __restrict__ ekeys, int kp, const float* __restrict__ qnorm,
+                                                             const float* __restrict__ thr, const unsigned* __restrict__ xnorm_max_bits,
+                                                             const float* __restrict__ qres, const int* __restrict__ overflow, int ld, int k,
+                                                             int64_t row_base, float* __restrict__ out_dist, int64_t* __restrict__ out_rows,
+                                                             int* __restrict__ flags) {
+    __shared__ uint64_t keys[KPRIME8], sorted[KPRIME8];
+    __shared__ int s_have;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_have = 0;
+    for (int i = tid; i < kp; i += 256) {
+        keys[i] = ekeys[(size_t)q * kp + i];
+        sorted[i] = SC_KEY_MAX;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < kp; i += 256) {
+        const uint64_t key = keys[i];
+        if (key == SC_KEY_MAX) continue;
+        int rank = 0;
+        for (int j = 0; j < kp; ++j) rank += (keys[j] < key) ? 1 : 0;  // exact keys are unique (row id in the low word)
+        sorted[rank] = key;
+        ++mine;
+    }
+    if (mine) atomicAdd(&s_have, mine);
+    __syncthreads();
+    const int have = s_have;
+    if (tid < k) {
+        const size_t o = (size_t)q * k + tid;
+        if (tid < have) {
+            out_dist[o] = sc_key_score(METRIC, sorted[tid]);
+            out_rows[o] = row_base + (int64_t)(uint32_t)sorted[tid];
+        } else {
+            out_dist[o] = (METRIC == SC_METRIC_L2) ? __builtin_inff() : -__builtin_inff();
+            out_rows[o] = -1;
+        }
+    }
+    if (tid == 0) {
+        int bad = overflow[q];
+        if (have == kp) {
+            const int kk = k < have ? k : have;
+            if (!certified<METRIC>(sorted[kk - 1], xnorm_max_bits, qnorm[q], qres[q], ld, thr[q])) bad = 1;
         }
         flags[q] = bad;
     }
 }
 
 __global__ __launch_bounds__(256) void scan_batched_init_kernel(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count,
-                                                                 int* overflow, int Q) {
+                                                                 int* overflow, int Q, int kp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < qpad) { thr[i] = __builtin_inff(); thr_fast[i] = __builtin_inff(); }
     if (i < Q) { count[i] = 0u; overflow[i] = 0; }
-    if (i < Q * KPRIME) best[i] = SC_KEY_MAX;
+    if (i < Q * kp) best[i] = SC_KEY_MAX;
 }
 
 // ------------------------------------------------------------------ launchers
-void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, hipStream_t s) {
-    const int n = Q * KPRIME > qpad ? Q * KPRIME : qpad;
-    hipLaunchKernelGGL(scan_batched_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, thr, thr_fast, qpad, best, count, overflow, Q);
+void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, int kp, hipStream_t s) {
+    const int n = Q * kp > qpad ? Q * kp : qpad;
+    hipLaunchKernelGGL(scan_batched_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, thr, thr_fast, qpad, best, count, overflow, Q, kp);
 }
 void sc_launch_shadow(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, void* Xb, unsigned* res_bits, hipStream_t s) {
     if (n <= 0) return;
     int64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, xnorm, first, n, ld, (bf16_t*)Xb, res_bits);
+}
+void sc_launch_shadow8(const float* X, const float* xnorm, int64_t first, int64_t n, int ld, int ld8, void* Xq, float* xscale, unsigned* res_bits,
+                       hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(shadow8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, xnorm, first, n, n, ld, ld8, (int8_t*)Xq, xscale, res_bits, (float*)nullptr);
 }
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s) {
     if (n <= 0) return;
@@ -496,36 +659,56 @@ void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipSt
 void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s) {
     hipLaunchKernelGGL(query_bf16_kernel, dim3((unsigned)((Qpad + 3) / 4)), dim3(256), 0, s, Qp, Q, Qpad, ld, (bf16_t*)Qb, qres);
 }
+// f32 padded queries [Q, ld] -> int8 [Qpad, ld8] (rows >= Q zero), qscale [Qpad], qres[q] = |q - s_q q_q|^2
+void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, hipStream_t s) {
+    hipLaunchKernelGGL(shadow8_kernel<true>, dim3((unsigned)((Qpad + 3) / 4)), dim3(256), 0, s, Qp, (const float*)nullptr, (int64_t)0, (int64_t)Q, (int64_t)Qpad, ld,
+                       ld8, (int8_t*)Qq, qscale, (unsigned*)nullptr, qres);
+}
 
 int sc_batched_kprime(void) { return KPRIME; }
+int sc_batched_kprime8(void) { return KPRIME8; }
 
+template <int METRIC, bool I8>
+static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+}
+
+// i8: Xb / Qb are the int8 shadows with rows of ld8 bytes (`ld` is then ld8), xscale / qscale their per-row scales; the batch must be
+// padded to 256 queries (the int8 stage only exists on the 256 x 256 tile)
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
-                           int cap, hipStream_t s) {
+                           int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale) {
     CoarseArgs a;
-    a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
-    a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap;
+    a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = i8 ? ld / 2 : ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
+    a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap; a.xscale = xscale; a.qscale = qscale;
     if ((Qpad % T_BN) == 0 && (row0 % T_BM) == 0) {  // large batches: 256 x 256 tiles (corpus rows are padded to 256)
         a.qtiles = Qpad / T_BN;
         a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);
-        const size_t lds256 = 4 * T_TILE_BYTES + 4 * 256 * 4;
-        static bool attr256 = false;
-        if (!attr256) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            attr256 = true;
-        }
-        dim3 grid256((unsigned)a.ntiles), block256(512);
         static const bool dbg = getenv("SC_COARSE_DBG") != nullptr;  // diagnostic: time the main loop alone (results invalid)
         if (dbg) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 1>), grid256, block256, lds256, s, a);
+            if (i8) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+                hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 1, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+                hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 1, false>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+            }
             return;
         }
-        if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_L2>, grid256, block256, lds256, s, a);
-        else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_COSINE>, grid256, block256, lds256, s, a);
-        else hipLaunchKernelGGL(scan_coarse256_kernel<SC_METRIC_IP>, grid256, block256, lds256, s, a);
+        if (i8) {
+            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, true>(a, s);
+            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, true>(a, s);
+            else launch_coarse256<SC_METRIC_IP, true>(a, s);
+        } else {
+            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, false>(a, s);
+            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, false>(a, s);
+            else launch_coarse256<SC_METRIC_IP, false>(a, s);
+        }
         return;
     }
     a.qtiles = Qpad / G_BN;
@@ -546,8 +729,8 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
 }
 
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
-                           float* thr_fast, int* overflow, int Q, hipStream_t s) {
-    const size_t lds = (size_t)(cap + 2 * KPRIME) * 8;
+                           float* thr_fast, int* overflow, int Q, int kp, hipStream_t s) {
+    const size_t lds = (size_t)(cap + 2 * kp) * 8;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -556,16 +739,32 @@ void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap,
         attr_done = true;
     }
     dim3 grid((unsigned)Q), block(SEL_THREADS);
-    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_L2>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
-    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_COSINE>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
-    else hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_IP>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_L2>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow, kp);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_COSINE>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow, kp);
+    else hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_IP>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow, kp);
 }
 
+template <int METRIC>
+static void launch_rerank(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best, const float* thr,
+                          const unsigned* bits, const float* qres, const int* overflow, int Q, int k, int64_t row_base, const uint32_t* perm,
+                          float* out_dist, int64_t* out_rows, int* flags, int kp, uint64_t* ekeys, hipStream_t s) {
+    if (kp == KPRIME) {
+        hipLaunchKernelGGL((scan_rerank_kernel<METRIC, false>), dim3((unsigned)Q), dim3(KPRIME), 0, s, X, xnorm, ld, Qp, qnorm, best, thr, bits, qres, overflow, k,
+                           row_base, perm, out_dist, out_rows, flags, kp, (uint64_t*)nullptr);
+        return;
+    }
+    hipLaunchKernelGGL((scan_rerank_kernel<METRIC, true>), dim3((unsigned)Q, (unsigned)(kp / KPRIME)), dim3(KPRIME), 0, s, X, xnorm, ld, Qp, qnorm, best, thr, bits,
+                       qres, overflow, k, row_base, perm, out_dist, out_rows, flags, kp, ekeys);
+    hipLaunchKernelGGL(scan_finalize_kernel<METRIC>, dim3((unsigned)Q), dim3(256), 0, s, ekeys, kp, qnorm, thr, bits, qres, overflow, ld, k, row_base, out_dist,
+                       out_rows, flags);
+}
+
+// kp = KPRIME: one fused kernel; kp = KPRIME8 (int8 stage): blocks of 128 candidates re-scored into ekeys [Q][kp], then sorted
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,
                            const float* thr, const unsigned* xnorm_max_bits, const float* qres, const int* overflow, int Q, int k,
-                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s) {
-    dim3 grid((unsigned)Q), block(KPRIME);
-    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_L2>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
-    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_COSINE>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
-    else hipLaunchKernelGGL(scan_rerank_kernel<SC_METRIC_IP>, grid, block, 0, s, X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, k, row_base, perm, out_dist, out_rows, flags);
+                           int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s, int kp,
+                           uint64_t* ekeys) {
+    if (metric == SC_METRIC_L2) launch_rerank<SC_METRIC_L2>(X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, Q, k, row_base, perm, out_dist, out_rows, flags, kp, ekeys, s);
+    else if (metric == SC_METRIC_COSINE) launch_rerank<SC_METRIC_COSINE>(X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, Q, k, row_base, perm, out_dist, out_rows, flags, kp, ekeys, s);
+    else launch_rerank<SC_METRIC_IP>(X, xnorm, ld, Qp, qnorm, best, thr, xnorm_max_bits, qres, overflow, Q, k, row_base, perm, out_dist, out_rows, flags, kp, ekeys, s);
 }

@@ -1,5 +1,6 @@
-"""GPU: the batched search path (bf16 MFMA coarse scan + exact f32 re-rank + certificate) returns exactly what
-the exact scan and the CPU oracle return: ids/order exact, distances bit-exact."""
+"""GPU: the batched search path (int8 / bf16 MFMA coarse scan + exact f32 re-rank + certificate) returns exactly what
+the exact scan and the CPU oracle return: ids/order exact, distances bit-exact -- whichever coarse stage answers
+(stage 0 = int8 first, then bf16, then the exact scan; 8 / 16 = that stage pinned)."""
 import numpy as np
 import pytest
 
@@ -18,30 +19,62 @@ def bits(a):
 def test_batched_equals_oracle_100k(rt, metric, nq):
     X = orc.synth(100_000, 768, seed=31)
     Q = orc.synth(nq, 768, seed=32)
+    od, orow = orc.search(X, Q, 10, metric)
     ix = _native.Index(rt, 768, metric=metric)
     ix.add(X)
     ix.set_search_mode("batched")
-    d, r = ix.search(Q, k=10)
-    st = ix.last_search_stats()
-    assert st["path"] == "batched"
-    od, orow = orc.search(X, Q, 10, metric)
-    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
-    assert st["uncertified"] <= nq // 4, st  # the certificate must hold for the bulk of gaussian queries
+    for stage in (0, 8, 16):
+        ix.set_coarse_stage(stage)
+        d, r = ix.search(Q, k=10)
+        st = ix.last_search_stats()
+        assert st["path"] == "batched" and st["coarse_bits"] == (16 if stage == 16 else 8), st
+        assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)), (stage, st)
+        # the certificates must hold for the bulk of gaussian queries, at either precision
+        assert st["uncertified"] <= nq // 4 and st["handed_to_bf16"] <= nq // 4, st
     ix.close()
 
 
 @pytest.mark.parametrize("n", [1, 100, 127, 128, 129, 1000, 5000])
 def test_batched_small_and_ragged(rt, n):
     rng = np.random.default_rng(n)
-    X = rng.standard_normal((n, 100)).astype(np.float32)
-    Q = rng.standard_normal((40, 100)).astype(np.float32)
-    ix = _native.Index(rt, 100, metric="L2", row_base=77)
+    for dim in (100, 192):  # row strides of 128 and 192 floats: the int8 rows are padded to whole 128-byte K-tiles
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        Q = rng.standard_normal((40, dim)).astype(np.float32)
+        od, orow = orc.search(X, Q, 7, "L2", row_base=77)
+        ix = _native.Index(rt, dim, metric="L2", row_base=77)
+        ix.add(X)
+        ix.set_search_mode("batched")
+        for stage in (8, 16):
+            ix.set_coarse_stage(stage)
+            d, r = ix.search(Q, k=7)
+            assert ix.last_search_stats()["path"] == "batched"
+            assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)), (dim, stage)
+        ix.close()
+
+
+def test_int8_stage_hands_hard_queries_on_and_switches_itself_off(rt):
+    """A corpus the int8 stage cannot separate (outlier dimensions blow up the per-row quantisation step): its uncertified
+    queries are answered by the bf16 stage, results stay exact, and the index starts later searches at the bf16 stage."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((50_000, 256)).astype(np.float32)
+    X[:, :4] = 300.0   # 4 constant outlier dimensions: every row's step is 300 / 127, the 252 informative dimensions round to 0 or +-1
+    Q = rng.standard_normal((64, 256)).astype(np.float32)
+    Q[:, :4] = 0.0     # neighbours are decided by the small dimensions, which bf16 keeps to 8 bits each
+    od, orow = orc.search(X, Q, 10, "L2")
+    ix = _native.Index(rt, 256, metric="L2")
     ix.add(X)
     ix.set_search_mode("batched")
-    d, r = ix.search(Q, k=7)
-    assert ix.last_search_stats()["path"] == "batched"
-    od, orow = orc.search(X, Q, 7, "L2", row_base=77)
+    d, r = ix.search(Q, k=10)
+    st = ix.last_search_stats()
+    assert st["coarse_bits"] == 8 and st["handed_to_bf16"] > 16, st
     assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    d, r = ix.search(Q, k=10)
+    st = ix.last_search_stats()
+    assert st["coarse_bits"] == 16 and st["handed_to_bf16"] == 0, st
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    ix.set_coarse_stage(0)  # clears the switch
+    ix.search(Q, k=10)
+    assert ix.last_search_stats()["coarse_bits"] == 8
     ix.close()
 
 
@@ -111,7 +144,13 @@ def test_full_size_batched_1024_queries_over_10m(rt):
     Q = orc.synth(1024, D, seed=1)
     d, r = ix.search(Q, k=K)
     st = ix.last_search_stats()
-    assert st["path"] == "batched" and st["uncertified"] <= 8, st
+    assert st["path"] == "batched" and st["coarse_bits"] == 8 and st["uncertified"] <= 8 and st["handed_to_bf16"] <= 32, st
+    ix.set_coarse_stage(16)  # the bf16 stage alone returns the very same thing
+    d16, r16 = ix.search(Q, k=K)
+    st16 = ix.last_search_stats()
+    assert st16["coarse_bits"] == 16 and st16["uncertified"] <= 8, st16
+    assert np.array_equal(r16, r) and np.array_equal(bits(d16), bits(d))
+    ix.set_coarse_stage(0)
     assert (np.diff(d, axis=1) >= 0).all() and ((r >= 0) & (r < N)).all()
     # returned distances are bit-exact f32 scores of the regenerated rows
     for qi in range(0, 1024, 97):
