@@ -161,8 +161,10 @@ sc_status sc_tokenizer_create(const char* vocab_utf8, size_t nbytes, int32_t low
 sc_status sc_tokenizer_destroy(sc_tokenizer* tok);
 sc_status sc_tokenizer_info(sc_tokenizer* tok, int32_t* vocab_size, int32_t* pad, int32_t* unk, int32_t* cls, int32_t* sep);
 /* texts i = bytes[offsets[i] .. offsets[i+1]) (UTF-8).  ids [n,S] ([CLS] pieces [SEP], truncated to min(max_tokens,S),
- * padded with [PAD]), lens [n].  A text containing a non-ASCII byte is NOT tokenised: needs_fallback[i] = 1, lens[i] = 0
- * (the Python tokenizer, which carries the Unicode rules, handles it).  threads <= 0: all hardware threads. */
+ * padded with [PAD]), lens [n].  Non-ASCII text is normalised as BERT's tokenizer does (NFD accent stripping and lower-casing for
+ * uncased vocabularies, CJK ideographs spaced out, Unicode punctuation and whitespace classes, control / format characters
+ * dropped; tables generated from the build image's transformers BertTokenizer, tests/golden/tokenizer_unicode.json).  Only a
+ * text that is not valid UTF-8 is left alone: needs_fallback[i] = 1, lens[i] = 0.  threads <= 0: all hardware threads. */
 sc_status sc_tokenizer_encode(sc_tokenizer* tok, const char* bytes, const int64_t* offsets, int32_t n, int32_t max_tokens, int32_t S,
                               int32_t* ids, int32_t* lens, uint8_t* needs_fallback, int32_t threads);
 
@@ -181,6 +183,9 @@ sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, 
  * {0: HW_ID, 1: XCC_ID, 2: entry, 3: main loop done, 4: epilogue issued, 5: stores drained}, stamps in 10 ns wall-clock
  * ticks.  Kernel tuning aid (scripts/gemm_trace.py). */
 sc_status sc_diag_gemm_trace(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* out, int64_t cap_words);
+/* The int8 form of the 256 x 256 tile (the batched scan's int8 coarse stage) on its own: out [M,N] i32 = A [M,K] i8 * W [N,K]^T,
+ * exact.  M, N multiples of 256, K multiple of 128. */
+sc_status sc_diag_gemm_i8(sc_runtime* rt, const int8_t* A, const int8_t* W, int32_t M, int32_t N, int32_t K, int32_t* out);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
 sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);
 

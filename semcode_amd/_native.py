@@ -74,6 +74,7 @@ SIGNATURES = {
     "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sc_diag_gemm_trace": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "sc_diag_gemm_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "sc_index_destroy": (C.c_int32, [C.c_void_p]),
@@ -539,7 +540,8 @@ class Encoder:
 
 
 class NativeTokenizer:
-    """C++ WordPiece (ASCII fast path, multi-threaded).  encode_batch returns which texts still need the Python tokenizer."""
+    """C++ WordPiece (ASCII fast path + BERT's Unicode normalisation, multi-threaded).  encode_batch also returns which texts it
+    left alone (malformed UTF-8 only)."""
 
     def __init__(self, vocab_path, lowercase: bool = True):
         data = Path(vocab_path).read_bytes()
@@ -605,6 +607,17 @@ def diag_gemm_trace(rt: Runtime, M: int, N: int, K: int, epi: int = 0, launches:
     nt = (M // 256) * (N // 256)
     out = np.zeros((launches, nt, 8), np.uint64)
     _check(lib().sc_diag_gemm_trace(rt.handle, epi, M, N, K, out.ctypes.data_as(C.c_void_p), out.size))
+    return out
+
+
+def diag_gemm_i8(rt: Runtime, A, W) -> np.ndarray:
+    """out [M,N] int32 = A [M,K] int8 @ W [N,K].T on the int8 form of the 256 tile (exact)."""
+    A = np.ascontiguousarray(A, np.int8)
+    W = np.ascontiguousarray(W, np.int8)
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), np.int32)
+    _check(lib().sc_diag_gemm_i8(rt.handle, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), M, N, K, out.ctypes.data_as(C.c_void_p)))
     return out
 
 

@@ -254,6 +254,40 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
     }
 }
 
+// ---- diagnostic: the int8 variant of the 256 tile main loop (scan_batched.hip's coarse stage) on its own, raw i32 accumulators out.
+// The A/B lane maps of v_mfma_i32_16x16x64_i8 are not documented in the guide ("check the map with exact integer data"): this
+// kernel is that check -- C[m][n] = sum_k A[m][k] * W[n][k] must hold exactly.
+__global__ __launch_bounds__(512) void gemm256_i8_diag_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ W, int32_t* __restrict__ C, int M, int N,
+                                                               int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_n = N / T_BN;
+    const int m0 = ((int)blockIdx.x / tiles_n) * T_BM, n0 = ((int)blockIdx.x % tiles_n) * T_BN;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile256_mainloop<0, NoTailHook, true>(reinterpret_cast<const bf16_t*>(A), K / 2, m0, reinterpret_cast<const bf16_t*>(W), K / 2, n0, K / 2, smem, acc, w, lane);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int wm = w >> 2, wn = w & 3, fr = ln & 15, fq = ln >> 4;
+    int32_t* out = C + (size_t)(m0 + wm * 128 + fr) * N + n0 + wn * 64 + 4 * fq;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(out + (size_t)(mi * 16) * N + ni * 16) = acc[ni][mi];
+}
+void sc_launch_gemm_i8_diag(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_i8_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm256_i8_diag_kernel, dim3((unsigned)((M / T_BM) * (N / T_BN))), dim3(512), T_LDS_BYTES, s, (const int8_t*)A, (const int8_t*)W, (int32_t*)C, M, N, K);
+}
+
 // M, N multiples of 128; K multiple of 64; all leading dimensions multiples of 8 elements.
 bool sc_gemm_bf16_supported(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && (M % G_BM) == 0 && (N % G_BN) == 0 && (K % G_BK) == 0; }
 

@@ -526,6 +526,25 @@ extern "C" sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float*
     return SC_OK;
 }
 
+void sc_launch_gemm_i8_diag(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s);
+
+extern "C" sc_status sc_diag_gemm_i8(sc_runtime* rt, const int8_t* A, const int8_t* W, int32_t M, int32_t N, int32_t K, int32_t* out) {
+    if (!rt || !A || !W || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_i8: NULL argument");
+    if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % 128)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_i8: need M%%256==0, N%%256==0, K%%128==0");
+    SC_HIP(hipSetDevice(rt->device));
+    hipStream_t s = rt->stream;
+    DevBuf da, dw, dc;
+    if (da.alloc((size_t)M * K) != hipSuccess || dw.alloc((size_t)N * K) != hipSuccess || dc.alloc((size_t)M * N * 4) != hipSuccess)
+        return sc_fail(SC_ERR_NOMEM, "diag: hipMalloc failed");
+    SC_HIP(hipMemcpyAsync(da.p, A, (size_t)M * K, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(dw.p, W, (size_t)N * K, hipMemcpyHostToDevice, s));
+    sc_launch_gemm_i8_diag(da.p, dw.p, dc.p, M, N, K, s);
+    SC_HIP(hipGetLastError());
+    SC_HIP(hipMemcpyAsync(out, dc.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
 extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out) {
     if (!rt || !qkv || !lens || !out || B < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_attention: bad argument");
     const int H = heads * 64;

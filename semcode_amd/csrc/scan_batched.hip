@@ -315,7 +315,10 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (I8) {
-                    const float av = (float)__builtin_bit_cast(int, acc[ni][mi][r]) * ar;
+                    // (the element is copied to a scalar first: hipcc lowers __builtin_bit_cast of a vector-element lvalue as a
+                    // load of element 0 -- every lane then tested its first query's score four times)
+                    const float bits = acc[ni][mi][r];
+                    const float av = (float)__builtin_bit_cast(int, bits) * ar;
                     t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
                 } else {
                     const float dot = acc[ni][mi][r];
@@ -331,7 +334,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
                 for (int r = 0; r < 4; ++r) {
                     if (row < a.row1 && t[r] <= tf[ni][r]) {
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
-                        const float dotv = I8 ? (float)__builtin_bit_cast(int, acc[ni][mi][r]) * (sx * sq[ni][r]) : acc[ni][mi][r];
+                        const float accv = acc[ni][mi][r];
+                        const float dotv = I8 ? (float)__builtin_bit_cast(int, accv) * (sx * sq[ni][r]) : accv;
                         const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries

@@ -134,7 +134,7 @@ class MI355XEmbeddings:
             self.tokenizer: Any = HashTokenizer(self._cfg["vocab"])
         else:
             self.tokenizer = WordPieceTokenizer(vocab)
-            if isinstance(vocab, (str, Path)):  # C++ fast path for ASCII texts; the Python tokenizer keeps the Unicode rules
+            if isinstance(vocab, (str, Path)):  # the C++ tokenizer (ASCII fast path + full Unicode normalisation, multi-threaded)
                 self._fast_tokenizer = _native.NativeTokenizer(vocab)
         self.dimension = self._cfg["hidden"]
 
@@ -163,7 +163,7 @@ class MI355XEmbeddings:
 
         smax = bucket_for(10 ** 9, self.max_tokens)
         ids, lens, fallback = self._fast_tokenizer.encode_batch(texts, self.max_tokens, smax)
-        for i in np.nonzero(fallback)[0]:  # texts with non-ASCII characters
+        for i in np.nonzero(fallback)[0]:  # only input that is not valid UTF-8 (cannot come out of a Python str)
             t = self.tokenizer.encode(texts[i], min(self.max_tokens, smax))
             ids[i, : len(t)] = t
             ids[i, len(t):] = self.tokenizer.pad_id

@@ -49,6 +49,61 @@ def test_basic_split_and_hash_tokenizer_are_deterministic():
     assert h.encode("") == [101, 102]
 
 
+def test_native_tokenizer_reproduces_committed_berttokenizer_ids(golden, tmp_path):
+    """tests/golden/tokenizer_unicode.json (oracle/gen_tokenizer_fixtures.py): 20 texts over Latin accents, CJK, Cyrillic, Greek,
+    Hangul, Arabic / Hebrew / Indic / Thai, emoji, control and format characters, full-width forms, > 100-character words --
+    ids of the in-container transformers BertTokenizer, uncased and cased, with and without truncation."""
+    import json
+
+    from semcode_amd import _native
+
+    g = json.loads((golden / "tokenizer_unicode.json").read_text())
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(g["vocab"]) + "\n", encoding="utf-8")
+    for name, want in g["ids"].items():
+        nat = _native.NativeTokenizer(vp, lowercase=name.startswith("uncased"))
+        max_tokens = int(name.split("_")[1])
+        ids, lens, fb = nat.encode_batch(g["texts"], max_tokens, 512, threads=2)
+        assert not fb.any()
+        for i, w in enumerate(want):
+            assert ids[i, : lens[i]].tolist() == w, (name, i, g["texts"][i][:40])
+        nat.close()
+
+
+def test_native_tokenizer_equals_berttokenizer_on_every_code_point(tmp_path):
+    """Live check against the in-container tokenizer: every code point (surrogates excepted), embedded between two letters, must
+    normalise and split exactly as BertTokenizer does -- the property the generated tables were built to have, checked end to end
+    through sc_tokenizer_encode with a vocabulary that makes each outcome visible."""
+    transformers = pytest.importorskip("transformers")
+    from semcode_amd import _native
+
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "a", "b", "##b", "ab", "##a"]
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    for lower in (True, False):
+        hf = transformers.BertTokenizer(str(vp), do_lower_case=lower)
+        nat = _native.NativeTokenizer(vp, lowercase=lower)
+        cps = [cp for cp in range(0x80, 0x110000, 1 if lower else 7) if not 0xD800 <= cp <= 0xDFFF]
+        for start in range(0, len(cps), 20000):
+            texts = ["a" + chr(cp) + "b" for cp in cps[start:start + 20000]]
+            want = hf(texts, truncation=True, max_length=16)["input_ids"]
+            ids, lens, fb = nat.encode_batch(texts, 16, 16)
+            assert not fb.any()
+            bad = [hex(cps[start + i]) for i, w in enumerate(want) if ids[i, : lens[i]].tolist() != w]
+            assert not bad, (lower, bad[:20])
+        nat.close()
+    # malformed UTF-8 cannot come out of a Python str; through the C ABI it is flagged, not guessed at
+    import ctypes as C
+
+    nat = _native.NativeTokenizer(vp)
+    blob, offs = b"ok \xff\xfe bad", np.array([0, 10], np.int64)
+    ids, lens, fb = np.zeros((1, 16), np.int32), np.zeros(1, np.int32), np.zeros(1, np.uint8)
+    st = _native.lib().sc_tokenizer_encode(nat._h, blob, offs.ctypes.data_as(C.c_void_p), 1, 16, 16, ids.ctypes.data_as(C.c_void_p),
+                                           lens.ctypes.data_as(C.c_void_p), fb.ctypes.data_as(C.c_void_p), 1)
+    assert st == 0 and fb[0] == 1 and lens[0] == 0
+    nat.close()
+
+
 def test_pack_buckets():
     assert [bucket_for(n) for n in (1, 32, 33, 64, 200, 256, 257, 512, 9999)] == [32, 32, 64, 64, 256, 256, 512, 512, 512]
     assert bucket_for(300, max_tokens=256) == 256
@@ -84,7 +139,7 @@ def test_factory_dispatch_and_error_types(monkeypatch):
             EmbeddingProviderFactory.create(provider="mi355x")
 
 
-def test_native_tokenizer_matches_python_and_flags_non_ascii(vocab_file):
+def test_native_tokenizer_matches_python_on_ascii_and_handles_unicode(vocab_file):
     import time
 
     from semcode_amd import _native
@@ -100,9 +155,13 @@ def test_native_tokenizer_matches_python_and_flags_non_ascii(vocab_file):
             want = py.encode(t, min(max_tokens, S))
             assert ids[i, : lens[i]].tolist() == want, (t[:40], max_tokens)
             assert (ids[i, lens[i]:] == nat.pad_id).all()
-    mixed = ["plain ascii", "café", "中文", "naive"]
+    # non-ASCII texts are tokenised natively too (NFD accent stripping, CJK spacing, Unicode punctuation: unicode_tables.h)
+    mixed = ["plain ascii", "café", "中文", "naive", TEXTS[3]]
     ids, lens, fb = nat.encode_batch(mixed, 64, 64)
-    assert fb.tolist() == [False, True, True, False] and lens[1] == 0
+    assert not fb.any()
+    for i, t in enumerate(mixed):
+        assert ids[i, : lens[i]].tolist() == py.encode(t, 64), t
+    assert ids[1, : lens[1]].tolist() == nat.encode_batch(["cafe"], 64, 64)[0][0, : lens[1]].tolist()  # accents are stripped
     # throughput sanity: the C++ path is much faster than the per-character Python path
     big = ["def f%d(x):\\n    return x + %d  # helper number %d\\n" % (i, i, i) * 20 for i in range(400)]
     t0 = time.perf_counter(); nat.encode_batch(big, 256, 256); t_nat = time.perf_counter() - t0
