@@ -75,6 +75,7 @@ void sc_ivf_drop_lists_locked(sc_index* ix) {
     ix->ivf_rows = 0;
     ix->trained = false;
     ix->shadow_rows = 0;
+    ix->shadow8_rows = 0;
 }
 
 // Xo[pos] = X[g[pos]] for the n stored rows, into fresh corpus-sized buffers that replace X / xnorm on success.
@@ -83,10 +84,11 @@ static sc_status ivf_move_rows_locked(sc_index* ix, const std::vector<uint32_t>&
     hipStream_t s = ix->rt->stream;
     const int64_t n = ix->n;
     SC_HIP(hipStreamSynchronize(s));
-    hipFree(ix->Xb);  // the layout changes: the shadow is rebuilt anyway
-    ix->Xb = nullptr;
-    ix->xb_cap = 0;
-    ix->shadow_rows = 0;
+    hipFree(ix->Xb);  // the layout changes: the shadows are rebuilt anyway
+    hipFree(ix->Xq);
+    ix->Xb = ix->Xq = nullptr;
+    ix->xb_cap = ix->xq_cap = 0;
+    ix->shadow_rows = ix->shadow8_rows = 0;
     Dev nx, nn;
     if (nx.alloc((size_t)ix->capacity * ix->ld * sizeof(float)) != hipSuccess || nn.alloc((size_t)ix->capacity * sizeof(float)) != hipSuccess ||
         d_g.alloc((size_t)n * 4) != hipSuccess)
@@ -154,7 +156,7 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<i
     ix->ivf_rows = n;
     ix->dirty_rows.clear();
     ix->nlist_trained = nlist;
-    ix->shadow_rows = 0;
+    ix->shadow_rows = ix->shadow8_rows = 0;
     ix->uncert_frac = -1.0;
     ix->trained = true;
     return SC_OK;
@@ -268,7 +270,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
         std::lock_guard<std::mutex> gq(qz->mu);
         sc_launch_ingest_rows(c_tight, nullptr, 0, nlist, dim, qz->X, qz->ld, qz->xnorm, s);
         qz->n = nlist;
-        qz->shadow_rows = 0;
+        qz->shadow_rows = qz->shadow8_rows = 0;  // the centroids changed: both coarse shadows are stale
     };
     set_centroids((const float*)d_cnew.p);
 

@@ -403,44 +403,113 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
 // tried on the encoder GEMMs it loses to hardware dispatch of one workgroup per tile; DESIGN.md section 8.
 
 // ------------------------------------------------------------------ per-phase selection: keep the kp (KPRIME or KPRIME8) best coarse keys
-// best [Q][kp] sorted keys (SC_KEY_MAX padded).  One workgroup per query.
+// best [Q][kp] keys in no particular order (SC_KEY_MAX padded).  One workgroup per query.
+//
+// The kp-th smallest of the n <= cap + kp keys (survivors of this phase + the previous best) is found by a radix select over
+// the 64-bit keys, 12 bits per pass from the top (4096-bin histogram in LDS, atomics; after the first pass only the keys of one
+// bin are still in play), then every key <= that pivot is kept -- exactly kp of them, keys being unique (row id in the low
+// word).  The rank sort this replaces was quadratic in n: 0.31 ms per step at kp = 128 and 2.6 ms at kp = 512
+// (gpurun_out/r2c_scan_i8.log); the re-rank never needed the list sorted.
+#define SEL_BINS 4096
 template <int METRIC>
 __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __restrict__ surv, unsigned* __restrict__ count, int cap,
                                                                    uint64_t* __restrict__ best, const float* __restrict__ qnorm,
                                                                    float* __restrict__ thr, float* __restrict__ thr_fast,
                                                                    int* __restrict__ overflow, int kp) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + kp] candidates, [kp] output
+    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + kp] candidates | hist[SEL_BINS] | scan[SEL_THREADS] | misc
     uint64_t* cand = sel_lds;
-    uint64_t* outk = sel_lds + cap + kp;
+    unsigned* hist = reinterpret_cast<unsigned*>(sel_lds + cap + kp);
+    unsigned* part = hist + SEL_BINS;          // per-thread partial sums of the bin scan
+    unsigned* misc = part + SEL_THREADS;       // [0] n, [1] chosen bin, [2] rank inside it, [3] output cursor
     const int q = blockIdx.x, tid = threadIdx.x;
     unsigned c = count[q];
     if (c > (unsigned)cap) {
         if (tid == 0) overflow[q] = 1;
         c = cap;
     }
-    const int n = (int)c + kp;
-    for (int i = tid; i < (int)c; i += SEL_THREADS) cand[i] = surv[(size_t)q * cap + i];
-    for (int i = tid; i < kp; i += SEL_THREADS) {
-        cand[c + i] = best[(size_t)q * kp + i];
-        outk[i] = SC_KEY_MAX;
+    if (tid == 0) { misc[0] = 0; misc[3] = 0; }
+    __syncthreads();
+    // gather the real keys (the previous best is padded with SC_KEY_MAX)
+    for (int i = tid; i < (int)c + kp; i += SEL_THREADS) {
+        const uint64_t key = i < (int)c ? surv[(size_t)q * cap + i] : best[(size_t)q * kp + (i - (int)c)];
+        if (key != SC_KEY_MAX) cand[atomicAdd(&misc[0], 1u)] = key;
     }
     __syncthreads();
-    // rank sort; keys are unique except for the SC_KEY_MAX padding, which never ranks below a real key
-    for (int e = tid; e < n; e += SEL_THREADS) {
-        const uint64_t key = cand[e];
-        if (key == SC_KEY_MAX) continue;
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (cand[j] < key) ? 1 : 0;
-        if (rank < kp) outk[rank] = key;
+    const int n = (int)misc[0];
+    uint64_t pivot = SC_KEY_MAX;  // keep every key <= pivot
+    bool have_kth = false;
+    if (n > kp) {
+        // radix select of rank kp - 1 (0-based): fixed high bits `prefix` (width 64 - shift - 12 ... ), remaining rank `want`
+        uint64_t prefix = 0;
+        unsigned want = (unsigned)(kp - 1);
+        for (int shift = 52; shift >= -8; shift -= 12) {  // 52, 40, 28, 16, 4, then the last 4 bits (shift -8 -> 4-bit digit)
+            const int sh = shift < 0 ? 0 : shift;
+            const int bits = shift < 0 ? 4 : 12;
+            const unsigned mask = (1u << bits) - 1u;
+            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            const int hi_shift = sh + bits;  // bits above the current digit must equal prefix
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const uint64_t key = cand[i];
+                if (hi_shift >= 64 || (key >> hi_shift) == prefix) atomicAdd(&hist[(unsigned)(key >> sh) & mask], 1u);
+            }
+            __syncthreads();
+            // bin scan: thread t owns bins [16 t, 16 t + 16)
+            unsigned local = 0;
+            for (int j = 0; j < SEL_BINS / SEL_THREADS; ++j) local += hist[tid * (SEL_BINS / SEL_THREADS) + j];
+            part[tid] = local;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned acc = 0;
+                int t = 0;
+                for (; t < SEL_THREADS; ++t) {
+                    if (acc + part[t] > want) break;
+                    acc += part[t];
+                }
+                int bin = t * (SEL_BINS / SEL_THREADS);
+                for (;; ++bin) {
+                    if (acc + hist[bin] > want) break;
+                    acc += hist[bin];
+                }
+                misc[1] = (unsigned)bin;
+                misc[2] = want - acc;
+            }
+            __syncthreads();
+            prefix = (prefix << bits) | (uint64_t)misc[1];
+            want = misc[2];
+            __syncthreads();
+        }
+        pivot = prefix;
+        have_kth = true;
+    } else if (n == kp) {
+        // exactly kp keys: all stay, the threshold is their maximum
+        uint64_t m = 0;
+        for (int i = tid; i < n; i += SEL_THREADS) m = cand[i] > m ? cand[i] : m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t o = ((uint64_t)__shfl_xor((unsigned)(m >> 32), off, 64) << 32) | (uint64_t)__shfl_xor((unsigned)m, off, 64);
+            m = o > m ? o : m;
+        }
+        uint64_t* wmax = reinterpret_cast<uint64_t*>(hist);
+        if ((tid & 63) == 0) wmax[tid >> 6] = m;
+        __syncthreads();
+        pivot = wmax[0];
+        for (int w = 1; w < SEL_THREADS / 64; ++w) pivot = wmax[w] > pivot ? wmax[w] : pivot;
+        have_kth = true;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint64_t key = cand[i];
+        if (key <= pivot) best[(size_t)q * kp + atomicAdd(&misc[3], 1u)] = key;
     }
     __syncthreads();
-    for (int i = tid; i < kp; i += SEL_THREADS) best[(size_t)q * kp + i] = outk[i];
+    const int kept = (int)misc[3];  // == min(n, kp)
+    for (int i = kept + tid; i < kp; i += SEL_THREADS) best[(size_t)q * kp + i] = SC_KEY_MAX;
     if (tid == 0) {
         count[q] = 0;
-        const uint64_t kth = outk[kp - 1];
         float t = __builtin_inff(), tf = __builtin_inff();
-        if (kth != SC_KEY_MAX) {
-            const float sc = sc_key_score(METRIC, kth);
+        if (have_kth) {
+            const float sc = sc_key_score(METRIC, pivot);
             t = (METRIC == SC_METRIC_L2) ? sc : -sc;
             const float slack = 1e-3f * fabsf(t) + 1e-6f;
             const float qn = qnorm[q];
@@ -734,7 +803,7 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
 
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
                            float* thr_fast, int* overflow, int Q, int kp, hipStream_t s) {
-    const size_t lds = (size_t)(cap + 2 * kp) * 8;
+    const size_t lds = (size_t)(cap + kp) * 8 + (SEL_BINS + SEL_THREADS + 8) * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
