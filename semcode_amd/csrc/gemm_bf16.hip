@@ -228,10 +228,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // DBG bits: 1 no in-loop DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads (ablations, outputs meaningless);
-    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0);
+    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0) | (DBG & (32 | 64));
     const int lda = a.ablock ? 64 : a.lda;
     const size_t a_kstep = a.ablock ? (size_t)a.M * 64 : (size_t)G_BK;
-    if (EPI == EPI_BIAS_RES && !DBG)
+    if (EPI == EPI_BIAS_RES && !(DBG & 31))
         gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
                                   ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
     else
@@ -430,7 +430,10 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
             case 21: launch256<EPI_BIAS, 21>(a, grid, block, s); return;
             default: break;
         }
-        launch256_epi<0>(epi, a, grid, block, s);
+        static const int var = getenv("SC_GEMM_VAR") ? atoi(getenv("SC_GEMM_VAR")) : 0;  // same-box A/B variants (gemm_tile.h)
+        if (var == 32) launch256_epi<32>(epi, a, grid, block, s);
+        else if (var == 64) launch256_epi<64>(epi, a, grid, block, s);
+        else launch256_epi<0>(epi, a, grid, block, s);
         return;
     }
     a.tiles_n = N / G_BN;

@@ -658,7 +658,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     // scratch layout
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_qres = carve((size_t)Q * 4);
+    const size_t o_qres = carve((size_t)Q * 4), o_amax = carve(16);
     const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
                  o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8);
@@ -674,7 +674,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     uint64_t *best = (uint64_t*)(b + o_best), *ekeys = (uint64_t*)(b + o_ek), *surv = (uint64_t*)(b + o_surv);
 
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, s);
+    if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
     else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
     int64_t r0 = 0, span = PHASE0_ROWS;

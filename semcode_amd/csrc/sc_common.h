@@ -110,7 +110,7 @@ void sc_launch_shadow8(const float* X, const float* xnorm, int64_t first, int64_
                        hipStream_t s);
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s);
 void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s);
-void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, hipStream_t s);
+void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, unsigned* absmax_bits, hipStream_t s);
 void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count, int* overflow, int Q, int kp, hipStream_t s);
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,

@@ -21,6 +21,7 @@
 // survivor list overflowed) are flagged and re-run through the exact scan by the host code.
 //
 // Roofline: MFMA bf16; algorithmic FLOPs = 2 * rows * ld * Qpad per phase launch.
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm_tile.h"
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void query_bf16_kernel(const float* __restrict
 template <bool QUERY>
 __global__ __launch_bounds__(256) void shadow8_kernel(const float* __restrict__ X, const float* __restrict__ xnorm, int64_t first, int64_t n, int64_t nout,
                                                        int ld, int ld8, int8_t* __restrict__ Xq, float* __restrict__ xscale,
-                                                       unsigned* __restrict__ res_bits, float* __restrict__ qres) {
+                                                       unsigned* __restrict__ res_bits, float* __restrict__ qres,
+                                                       const unsigned* __restrict__ common_absmax_bits) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float* __restrict__ 
             }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (QUERY) m = __builtin_bit_cast(float, *common_absmax_bits);  // queries: ONE scale for the batch (the epilogue's prefilter relies on it)
         const float sc = m > 0.f ? m * (1.0f / 127.0f) : 1.0f;
         const float inv = 1.0f / sc;
         float res = 0.f;
@@ -168,6 +171,15 @@ __global__ __launch_bounds__(256) void shadow8_kernel(const float* __restrict__ 
         atomicMax(res_bits, __builtin_bit_cast(unsigned, worst * 1.0001f));
         atomicMax(res_bits + 1, __builtin_bit_cast(unsigned, worst_rel * 1.0001f));
     }
+}
+
+// max |q_i| over the whole query batch (non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ Qp, int64_t n, unsigned* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(Qp[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
 }
 
 // ------------------------------------------------------------------ coarse GEMM + filter
@@ -266,7 +278,7 @@ static __device__ __forceinline__ void coarse256_stage(const CoarseArgs& a, int6
     }
     if (tid < 256) {
         const int q = n0 + tid;
-        q_tf[tid] = a.thr_fast[q];  // padded to Qpad and +inf-initialised
+        q_tf[tid] = q < a.Q ? a.thr_fast[q] : -__builtin_inff();  // padding never passes (and does not loosen the lane's prefilter bound)
         q_tf[256 + tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
         q_tf[512 + tid] = q < a.Q ? a.qnorm[q] : 1.0f;
         if (I8) q_tf[1024 + tid] = a.qscale[q];  // padded to Qpad
@@ -297,6 +309,10 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         tf[ni] = *reinterpret_cast<const f32x4*>(q_tf + wn * 64 + ni * 16 + 4 * fq);
         if (I8) sq[ni] = *reinterpret_cast<const f32x4*>(q_tf + 1024 + wn * 64 + ni * 16 + 4 * fq);
     }
+    float tfmax = -__builtin_inff();  // loosest fast threshold among this lane's 16 queries
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) tfmax = fmaxf(fmaxf(tfmax, fmaxf(tf[ni][0], tf[ni][1])), fmaxf(tf[ni][2], tf[ni][3]));
+    const float sq0 = I8 ? sq[0][0] : 1.0f;  // the batch's common query scale
     // hits of this lane: up to 4 queued (local query index, key); a 5th and later ones are flushed directly
     int nh = 0;
     int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
@@ -308,17 +324,34 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
         const float sx = I8 ? q_tf[1280 + rl] : 0.f;  // int8 stage: the integer dot is scaled by s_r s_q
         const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
+        // Prefilter: ONE compare per score.  The fast test t <= tf_q is  dot >= (base_r - tf_q) / c_r  with base_r = |x|^2 (L2) or
+        // 0 and c_r = 2 (L2), 1 (IP), 1/|x| (cosine), times s_r s_q in the int8 stage, where every query of the batch shares one
+        // scale (sc_launch_query_i8) -- so the right-hand side differs between this lane's 16 queries only through tf_q, and with
+        // tfmax = max of those it is bounded below by a per-row constant.  Anything that passes is tested precisely below.
+        float Tlb;
+        if (I8) Tlb = ((METRIC == SC_METRIC_L2 ? xn : 0.f) - tfmax) / (-ar * sq0);
+        else Tlb = (METRIC == SC_METRIC_L2) ? 0.5f * (xn - tfmax) : (METRIC == SC_METRIC_COSINE) ? -tfmax / xs : -tfmax;
+        Tlb = Tlb - fabsf(Tlb) * 4e-6f - (I8 ? 2.0f : 0.f);  // rounding of this bound itself (the precise test has its own slack)
+        int Ti = 0;
+        if (I8) Ti = !(Tlb == Tlb) ? (int)0x80000000 : Tlb <= -2.0e9f ? (int)0x80000000 : Tlb >= 2.0e9f ? 0x7FFFFFFF : (int)Tlb - 1;
+        if (!I8 && !(Tlb == Tlb)) Tlb = -__builtin_inff();  // NaN (0 * inf on an all-zero row): let the precise test decide
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
+            bool g;
+            if (I8) {
+                const int a0 = __float_as_int(acc[ni][mi][0]), a1 = __float_as_int(acc[ni][mi][1]), a2 = __float_as_int(acc[ni][mi][2]),
+                          a3 = __float_as_int(acc[ni][mi][3]);
+                g = (a0 >= Ti) | (a1 >= Ti) | (a2 >= Ti) | (a3 >= Ti);
+            } else {
+                g = (acc[ni][mi][0] >= Tlb) | (acc[ni][mi][1] >= Tlb) | (acc[ni][mi][2] >= Tlb) | (acc[ni][mi][3] >= Tlb);
+            }
+            if (!__any(g)) continue;
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (I8) {
-                    // (the element is copied to a scalar first: hipcc lowers __builtin_bit_cast of a vector-element lvalue as a
-                    // load of element 0 -- every lane then tested its first query's score four times)
-                    const float bits = acc[ni][mi][r];
-                    const float av = (float)__builtin_bit_cast(int, bits) * ar;
+                    const float av = (float)__float_as_int(acc[ni][mi][r]) * ar;
                     t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
                 } else {
                     const float dot = acc[ni][mi][r];
@@ -327,15 +360,14 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
                     else t[r] = -dot;
                 }
             }
-            const bool g = (t[0] <= tf[ni][0]) | (t[1] <= tf[ni][1]) | (t[2] <= tf[ni][2]) | (t[3] <= tf[ni][3]);
-            if (__any(g)) {
+            {
                 const int64_t row = m0 + rl;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (row < a.row1 && t[r] <= tf[ni][r]) {
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
                         const float accv = acc[ni][mi][r];
-                        const float dotv = I8 ? (float)__builtin_bit_cast(int, accv) * (sx * sq[ni][r]) : accv;
+                        const float dotv = I8 ? (float)__float_as_int(accv) * (sx * sq[ni][r]) : accv;
                         const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries
@@ -454,19 +486,22 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
                 if (hi_shift >= 64 || (key >> hi_shift) == prefix) atomicAdd(&hist[(unsigned)(key >> sh) & mask], 1u);
             }
             __syncthreads();
-            // bin scan: thread t owns bins [16 t, 16 t + 16)
+            // bin scan: thread t owns bins [16 t, 16 t + 16); exclusive prefix over the threads by wave shuffles + 4 wave totals
             unsigned local = 0;
             for (int j = 0; j < SEL_BINS / SEL_THREADS; ++j) local += hist[tid * (SEL_BINS / SEL_THREADS) + j];
-            part[tid] = local;
+            unsigned incl = local;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(incl, off, 64);
+                if ((tid & 63) >= off) incl += o;
+            }
+            if ((tid & 63) == 63) part[tid >> 6] = incl;
             __syncthreads();
-            if (tid == 0) {
-                unsigned acc = 0;
-                int t = 0;
-                for (; t < SEL_THREADS; ++t) {
-                    if (acc + part[t] > want) break;
-                    acc += part[t];
-                }
-                int bin = t * (SEL_BINS / SEL_THREADS);
+            unsigned pre = incl - local;
+            for (int w = 0; w < (tid >> 6); ++w) pre += part[w];
+            if (pre <= want && want < pre + local) {  // exactly one thread: the wanted rank falls into its 16 bins
+                unsigned acc = pre;
+                int bin = tid * (SEL_BINS / SEL_THREADS);
                 for (;; ++bin) {
                     if (acc + hist[bin] > want) break;
                     acc += hist[bin];
@@ -721,7 +756,8 @@ void sc_launch_shadow8(const float* X, const float* xnorm, int64_t first, int64_
     if (n <= 0) return;
     int64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(shadow8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, xnorm, first, n, n, ld, ld8, (int8_t*)Xq, xscale, res_bits, (float*)nullptr);
+    hipLaunchKernelGGL(shadow8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, xnorm, first, n, n, ld, ld8, (int8_t*)Xq, xscale, res_bits, (float*)nullptr,
+                       (const unsigned*)nullptr);
 }
 void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipStream_t s) {
     if (n <= 0) return;
@@ -732,10 +768,14 @@ void sc_launch_norm_max(const float* xnorm, int64_t n, unsigned* out_bits, hipSt
 void sc_launch_query_bf16(const float* Qp, int Q, int Qpad, int ld, void* Qb, float* qres, hipStream_t s) {
     hipLaunchKernelGGL(query_bf16_kernel, dim3((unsigned)((Qpad + 3) / 4)), dim3(256), 0, s, Qp, Q, Qpad, ld, (bf16_t*)Qb, qres);
 }
-// f32 padded queries [Q, ld] -> int8 [Qpad, ld8] (rows >= Q zero), qscale [Qpad], qres[q] = |q - s_q q_q|^2
-void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, hipStream_t s) {
+// f32 padded queries [Q, ld] -> int8 [Qpad, ld8] (rows >= Q zero) with ONE scale s = max |q_i| / 127 for the whole batch
+// (qscale [Qpad] all equal), qres[q] = |q - s q_q|^2; absmax_bits: 4 bytes of device scratch
+void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void* Qq, float* qscale, float* qres, unsigned* absmax_bits, hipStream_t s) {
+    hipMemsetAsync(absmax_bits, 0, 4, s);
+    const int64_t n = (int64_t)Q * ld;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, s, Qp, n, absmax_bits);
     hipLaunchKernelGGL(shadow8_kernel<true>, dim3((unsigned)((Qpad + 3) / 4)), dim3(256), 0, s, Qp, (const float*)nullptr, (int64_t)0, (int64_t)Q, (int64_t)Qpad, ld,
-                       ld8, (int8_t*)Qq, qscale, (unsigned*)nullptr, qres);
+                       ld8, (int8_t*)Qq, qscale, (unsigned*)nullptr, qres, (const unsigned*)absmax_bits);
 }
 
 int sc_batched_kprime(void) { return KPRIME; }
