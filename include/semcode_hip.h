@@ -126,6 +126,11 @@ sc_status sc_encoder_blob_bytes(const sc_encoder_cfg* cfg, int64_t* out);
 sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg, const void* weights_blob, size_t nbytes, sc_encoder** out);
 sc_status sc_encoder_destroy(sc_encoder* enc);
 sc_status sc_encoder_info(sc_encoder* enc, sc_encoder_cfg* cfg_out);
+/* The forward has two pipelines with the same arithmetic up to rounding: batches of more than 1 024 token rows run 256 x 256-tile
+ * GEMMs with every LayerNorm folded into the neighbouring GEMMs (statistics from the producing epilogue, normalisation in the
+ * consuming one: no LayerNorm kernel); smaller batches -- a query -- run split-K GEMMs with stand-alone LayerNorm kernels.
+ * path 0 = that rule, 1 = the batch pipeline for every size, 2 = the small-batch pipeline for every size (tests, A/B runs). */
+sc_status sc_encoder_set_path(sc_encoder* enc, int32_t path);
 /* Replaces Embeddings.embed_documents / embed_query after tokenisation (indexer.py:150,
  * pipeline.py:171-175): ids [B,S] int32 (S in {32,64,128,256,512}, padded by the caller), lens [B] =
  * number of real tokens per row (keys >= len are masked, pooling = mean over the first len tokens),

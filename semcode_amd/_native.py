@@ -61,6 +61,7 @@ SIGNATURES = {
     "sc_encoder_blob_bytes": (C.c_int32, [C.POINTER(EncoderCfg), C.POINTER(C.c_int64)]),
     "sc_encoder_create": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "sc_encoder_destroy": (C.c_int32, [C.c_void_p]),
+    "sc_encoder_set_path": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_encoder_info": (C.c_int32, [C.c_void_p, C.POINTER(EncoderCfg)]),
     "sc_encoder_embed_ids": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_encoder_embed_ids_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -498,6 +499,10 @@ class Encoder:
         if not self._h:
             raise RuntimeError("encoder is closed")
         return self._h
+
+    def set_path(self, path: str) -> None:
+        """'auto' | 'batch' (LayerNorm-folded 256-tile pipeline for every size) | 'small' (split-K + LayerNorm kernels)."""
+        _check(lib().sc_encoder_set_path(self.handle, {"auto": 0, "batch": 1, "small": 2}[path]))
 
     def embed_ids(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         """ids [B, S] int32 with S in SEQ_BUCKETS, lens [B] -> [B, hidden] f32."""

@@ -91,6 +91,148 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------ LayerNorm-folded batch pipeline (sc_encoder.cpp, gemm_bf16.hip EPI_LNA_* / EPI_RESLN_STATS)
+// Embeddings WITHOUT their LayerNorm: the raw sum (bf16) plus the row statistics the consuming GEMM folds in -- slot 0 of
+// stats [slots][tokens_pad][2] gets (sum, sum of squares) of the bf16-ROUNDED row, the other slots zero (a GEMM-produced tensor
+// fills one slot per 256 columns).
+__global__ __launch_bounds__(256) void embed_raw_kernel(const int32_t* __restrict__ ids, int tokens, int tokens_pad, int S, int H, int vocab, int max_pos,
+                                                         const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                         const float* __restrict__ temb, bf16_t* __restrict__ out, float* __restrict__ stats, int slots) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= tokens_pad) return;
+    float s1 = 0.f, s2 = 0.f;
+    if (tok < tokens) {
+        int id = ids[tok];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        int pos = tok % S;
+        pos = pos >= max_pos ? max_pos - 1 : pos;
+        const float* we = wemb + (size_t)id * H;
+        const float* pe = pemb ? pemb + (size_t)pos * H : nullptr;
+        bf16_t* o = out + (size_t)tok * H;
+#pragma unroll
+        for (int j = 0; j < LN_MAXJ; ++j) {
+            const int k0 = 4 * lane + 256 * j;
+            if (k0 < H) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(we + k0);
+                if (pe) v += *reinterpret_cast<const f32x4*>(pe + k0);
+                v += *reinterpret_cast<const f32x4*>(temb + k0);
+                u16x4 r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    r[c] = f2bf(v[c]);
+                    const float y = bf2f(r[c]);
+                    s1 += y;
+                    s2 = fmaf(y, y, s2);
+                }
+                *reinterpret_cast<u16x4*>(o + k0) = r;
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+    } else {
+        // padding rows (tokens .. tokens_pad, never read by attention or pooling): zeros with statistics (0, 0), so that whatever the
+        // row-independent GEMMs compute for them stays finite (mu 0, rs 1/sqrt(eps), times zero)
+        for (int k0 = 4 * lane; k0 < H; k0 += 256) *reinterpret_cast<u16x4*>(out + (size_t)tok * H + k0) = u16x4{0, 0, 0, 0};
+    }
+    if (lane < slots) {
+        float* p = stats + ((size_t)lane * tokens_pad + tok) * 2;
+        p[0] = lane == 0 ? s1 : 0.f;
+        p[1] = lane == 0 ? s2 : 0.f;
+    }
+}
+
+// W' = bf16(W diag(gamma)), c1[n] = sum_k W'[n,k] (of the ROUNDED values: it cancels what the MFMA accumulates),
+// c2[n] = bias[n] + sum_k beta[k] W[n,k].  One wave per output row n.
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ bias, int N, int K, bf16_t* __restrict__ Wf,
+                                                               float* __restrict__ c1, float* __restrict__ c2) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k0 = 4 * lane; k0 < K; k0 += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k0);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k0);
+        u16x4 r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r[c] = f2bf(w[c] * g[c]);
+            s1 += bf2f(r[c]);
+            s2 = fmaf(b[c], w[c], s2);
+        }
+        *reinterpret_cast<u16x4*>(Wf + (size_t)n * K + k0) = r;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        c1[n] = s1;
+        c2[n] = (bias ? bias[n] : 0.f) + s2;
+    }
+}
+__global__ __launch_bounds__(256) void add_vectors_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// masked mean pooling of LayerNorm(y) computed on the fly from the raw rows and their partial statistics:
+// mean_t LN(y_t) = gamma * (sum_t rs_t y_t - sum_t rs_t mu_t) / len + beta.  One workgroup per (chunk, 256 columns).
+__global__ __launch_bounds__(256) void mean_pool_ln_kernel(const bf16_t* __restrict__ y, const float* __restrict__ stats, int slots, int tokens_pad,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            const int32_t* __restrict__ lens, int S, int H, float* __restrict__ out) {
+    __shared__ float part[8][32][9];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y, cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int k0 = blockIdx.x * 256 + cc * 8;
+    int len = lens[b];
+    len = len < 1 ? 1 : (len > S ? S : len);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accmu = 0.f;
+    const float inv_h = 1.0f / (float)H;
+    if (k0 < H) {
+        const bf16_t* p = y + (size_t)b * S * H + k0;
+#pragma unroll 2
+        for (int s0 = rg; s0 < len; s0 += 8) {
+            const size_t tok = (size_t)b * S + s0;
+            float s1 = 0.f, s2 = 0.f;
+            for (int t = 0; t < slots; ++t) {
+                s1 += stats[((size_t)t * tokens_pad + tok) * 2];
+                s2 += stats[((size_t)t * tokens_pad + tok) * 2 + 1];
+            }
+            const float mu = s1 * inv_h;
+            const float rs = 1.0f / sqrtf(fmaxf(s2 * inv_h - mu * mu, 0.f) + eps);
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(p + (size_t)s0 * H);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[2 * c] = fmaf(rs, __builtin_bit_cast(float, raw[c] << 16), acc[2 * c]);
+                acc[2 * c + 1] = fmaf(rs, __builtin_bit_cast(float, raw[c] & 0xFFFF0000u), acc[2 * c + 1]);
+            }
+            accmu = fmaf(rs, mu, accmu);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part[rg][cc][c] = acc[c];
+    part[rg][cc][8] = accmu;
+    __syncthreads();
+    if (rg == 0 && k0 < H) {
+        const float inv = 1.0f / (float)len;
+        float m = part[0][cc][8];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) m += part[g][cc][8];
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = part[0][cc][c];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += part[g][cc][c];
+            o[c] = fmaf((t - m) * inv, gamma[k0 + c], beta[k0 + c]);
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)b * H + k0) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(out + (size_t)b * H + k0 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm (input already holds x + sublayer(x))
 // HBM-bound (2 x tokens x H x 2 B).  Half a wave per token: lane l of the half owns the 16-byte chunks l, l + 32, ... of
 // the row (8 bf16 each; H = 768 -> 3 per lane), so one load instruction moves 2 x 512 B.  Workgroups walk the rows with
@@ -572,6 +714,23 @@ void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H
         hipLaunchKernelGGL(mean_pool_sliced_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)B), dim3(256), 0, s, (const bf16_t*)x, lens, S, H, out);
     else
         hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x, lens, S, H, normalize, out);
+}
+void sc_launch_embed_raw(const int32_t* ids, int tokens, int tokens_pad, int S, int H, int vocab, int max_pos, const float* wemb, const float* pemb,
+                         const float* temb, void* out, float* stats, int slots, hipStream_t s) {
+    hipLaunchKernelGGL(embed_raw_kernel, dim3((unsigned)((tokens_pad + 3) / 4)), dim3(256), 0, s, ids, tokens, tokens_pad, S, H, vocab, max_pos, wemb, pemb, temb,
+                       (bf16_t*)out, stats, slots);
+}
+void sc_launch_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, void* Wf, float* c1, float* c2,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, gamma, beta, bias, N, K, (bf16_t*)Wf, c1, c2);
+}
+void sc_launch_add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(add_vectors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+}
+void sc_launch_mean_pool_ln(const void* y, const float* stats, int slots, int tokens_pad, const float* gamma, const float* beta, float eps,
+                            const int32_t* lens, int B, int S, int H, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_pool_ln_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)B), dim3(256), 0, s, (const bf16_t*)y, stats, slots, tokens_pad, gamma,
+                       beta, eps, lens, S, H, out);
 }
 void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
     if (n <= 0) return;

@@ -23,7 +23,12 @@
 
 #include "gemm_tile.h"
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
+// EPI_LNA_*: the A operand is a PRE-LayerNorm tensor y (raw bf16 rows) and the weights carry the LayerNorm's gamma
+// (W' = W diag(gamma)): with the row statistics mu, rs of y,  LN(y) W^T + b = rs (y W'^T - mu c1) + c2,  c1[n] = sum_k W'[n,k],
+// c2[n] = b[n] + sum_k beta[k] W[n,k] -- the normalisation becomes two FMAs in the epilogue and the LayerNorm kernel disappears.
+// EPI_RESLN_STATS: bias + LayerNorm(residual) applied on the fly ((r - mu) rs g + beta, beta folded into the bias), and the
+// row sums / sums of squares of THIS output (after its bf16 rounding) written per 256-column tile for the consumer's statistics.
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_LNA_BIAS = 3, EPI_LNA_GELU = 4, EPI_RESLN_STATS = 5 };
 
 struct GemmArgs {
     const bf16_t* A;   // [M, lda]
@@ -41,6 +46,14 @@ struct GemmArgs {
     int nt;            // 256-tile kernel: write C with non-temporal stores (outputs far larger than L2)
     int cblock;        // 1: C is stored as [N / 64][M][64] (64-column blocks, each contiguous over the rows) instead of [M][ldc]
     int ablock;        // 1: A is stored that way, [K / 64][M][64] (256-tile kernel only)
+    // LayerNorm fold (EPI_LNA_*, EPI_RESLN_STATS; 256-tile kernel only)
+    const float* c1;         // EPI_LNA_*: [N] column sums of the bf16 W' (bias = c2)
+    const float* stats_in;   // EPI_LNA_*: [slots][M][2] partial (sum, sum of squares) of the A tensor's rows, one slot per 256 columns of it
+    int stat_slots;          //            K / 256
+    float* fin;              // EPI_LNA_*: out, EPI_RESLN_STATS: in -- [M][2] finalised (mu, rs) of those rows
+    const float* gam;        // EPI_RESLN_STATS: [N] gamma of the residual's LayerNorm (its beta is folded into bias)
+    float* stats_out;        // EPI_RESLN_STATS: [N / 256][M][2] partial sums of this output's rows
+    float ln_eps;
 };
 
 // address of C[m][n] (n % 4 == 0 where vectors are stored): row-major, or 64-column blocks that are contiguous over the rows --
@@ -141,6 +154,34 @@ struct ResidualTailHook {
     }
 };
 
+// EPI_LNA_*: the partial row sums of this wave's 128 rows, stat_slots pieces of 1 KiB (128 rows x {sum, sumsq} f32), into the wave's
+// own slice of the dead pipeline buffers, under the last 32 MFMAs.
+struct LnaTailHook {
+    const float* stats;  // stats_in + (m0 + wm * 128) * 2, slot stride = M * 2 floats
+    size_t slot_stride;
+    int slots, w, lane;
+    char* smem;
+    __device__ __forceinline__ void operator()() const {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        char* dst = smem + w * 16384;
+        for (int sl = 0; sl < slots; ++sl)
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(stats + sl * slot_stride + ln * 4), (lds_vptr)(dst + sl * 1024), 16, 0, 0);
+    }
+};
+// EPI_RESLN_STATS: the residual tile as in ResidualTailHook, plus the finalised (mu, rs) of this wave's 128 rows (1 KiB) into its
+// epilogue staging slice (read into registers before the first staging write).
+struct ResLnTailHook {
+    ResidualTailHook res;
+    const float* fin;  // fin + (m0 + wm * 128) * 2
+    __device__ __forceinline__ void operator()() const {
+        res();
+        int ln = res.lane;
+        asm volatile("" : "+v"(ln));
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(fin + ln * 4), (lds_vptr)(res.smem + 4 * T_TILE_BYTES + res.w * (16 * T_EPI_ROW)), 16, 0, 0);
+    }
+};
+
 // Epilogue: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row segments per store).  Each
 // wave stages one 16-row x 64-column block at a time as bf16 in its private LDS slice BEHIND the pipeline buffers and
 // stores whole 128-byte row segments, 16 B per lane.  bias, GELU and the residual (read from LDS, see above) are applied
@@ -205,6 +246,155 @@ static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m
     }
 }
 
+// ---- LayerNorm-folded epilogues --------------------------------------------------------------------------------------
+// EPI_LNA_BIAS / EPI_LNA_GELU: out = rs_m (acc - mu_m c1[n]) + c2[n] (+ GELU).  (mu, rs) of a row come from the partial sums the
+// producing GEMM left per 256-column tile of the A tensor (LnaTailHook put this wave's 128 rows x slots into its pipeline slice);
+// the column tile n0 == 0 also publishes them finalised ([M][2]) for the residual epilogue of the next GEMM.
+template <int EPI>
+static __device__ __forceinline__ void gemm256_epilogue_lna(const GemmArgs& a, int m0, int n0, char* smem, int w, int lane, f32x4 (&acc)[4][8]) {
+    const int wm = w >> 2, wn = w & 3;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    __builtin_amdgcn_sched_barrier(0);
+    const int fr = ln & 15, fq = ln >> 4;
+    const int prow = ln >> 3, c8 = (ln & 7) * 8;
+    char* stg = smem + 4 * T_TILE_BYTES + w * (16 * T_EPI_ROW);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x4 c1v[4], c2v[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        c1v[ni] = *reinterpret_cast<const f32x4*>(a.c1 + n0 + wn * 64 + ni * 16 + 4 * fq);
+        c2v[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's statistics DMA has landed
+    const char* sl = smem + w * 16384 + fr * 8;
+    const float inv_k = 1.0f / (float)a.K;
+    const size_t crs = a.cblock ? 64 : (size_t)a.ldc;
+    bf16_t* cp = a.C + c_index(a, m0 + wm * 128 + prow, n0 + wn * 64) + c8;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = 0; t < a.stat_slots; ++t) {
+            const f32x2_t p = *reinterpret_cast<const f32x2_t*>(sl + t * 1024 + mi * 128);
+            s1 += p[0];
+            s2 += p[1];
+        }
+        const float mu = s1 * inv_k;
+        const float var = fmaxf(s2 * inv_k - mu * mu, 0.f);
+        const float rs = 1.0f / sqrtf(var + a.ln_eps);
+        if (n0 == 0 && wn == 0 && fq == 0) *reinterpret_cast<f32x2_t*>(a.fin + (size_t)(m0 + wm * 128 + mi * 16 + fr) * 2) = f32x2_t{mu, rs};
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(rs, fmaf(-mu, c1v[ni][r], acc[ni][mi][r]), c2v[ni][r]);
+            if (EPI == EPI_LNA_GELU) {
+                const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
+            *reinterpret_cast<u32x2*>(stg + fr * T_EPI_ROW + (ni * 16 + 4 * fq) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg + (j * 8 + prow) * T_EPI_ROW + c8 * 2);
+            bf16_t* dst = cp + (size_t)(mi * 16 + j * 8) * crs;
+            if (a.nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+            else *reinterpret_cast<u32x4*>(dst) = o;
+        }
+    }
+}
+
+// EPI_RESLN_STATS: out = acc + bias[n] + (r - mu_m) rs_m gam[n]   (r = the raw pre-LayerNorm residual, bias already holds + beta),
+// and the partial sums (sum, sum of squares) of this tile's 256 columns of the bf16-ROUNDED output, per row, into stats_out.
+static __device__ __forceinline__ void gemm256_epilogue_resln(const GemmArgs& a, int m0, int n0, char* smem, int w, int lane, f32x4 (&acc)[4][8]) {
+    const int wm = w >> 2, wn = w & 3;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    __builtin_amdgcn_sched_barrier(0);
+    const int fr = ln & 15, fq = ln >> 4;
+    const int prow = ln >> 3, c8 = (ln & 7) * 8;
+    char* stg = smem + 4 * T_TILE_BYTES + w * (16 * T_EPI_ROW);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x4 bias4[4], gam4[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
+        gam4[ni] = *reinterpret_cast<const f32x4*>(a.gam + n0 + wn * 64 + ni * 16 + 4 * fq);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // residual tile + row statistics have landed
+    f32x2_t st[8];  // (mu, rs) of this lane's 8 rows: out of the staging slice before it is written
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) st[mi] = *reinterpret_cast<const f32x2_t*>(stg + (mi * 16 + fr) * 8);
+    const char* rlds = smem + w * 16384 + fr * 128 + (fq & 1) * 8;
+    const int swz = (fr >> 1) & 7;
+    auto read_res = [&](int mi, u32x2 (&dst)[4]) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const u32x2*>(rlds + mi * 2048 + (((ni * 2 + (fq >> 1)) ^ swz) << 4));
+    };
+    u32x2 rr[2][4];  // residual of row block mi (one ahead: LDS reads cannot be moved across the staging writes by the compiler)
+    read_res(0, rr[0]);
+    float sum1[8], sum2[8];
+    const size_t crs = a.cblock ? 64 : (size_t)a.ldc;
+    bf16_t* cp = a.C + c_index(a, m0 + wm * 128 + prow, n0 + wn * 64) + c8;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        if (mi + 1 < 8) read_res(mi + 1, rr[(mi + 1) & 1]);
+        const float mu = st[mi][0], rs = st[mi][1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const u32x2 r2 = rr[mi & 1][ni];
+            const f32x4 rv = f32x4{__builtin_bit_cast(float, r2[0] << 16), __builtin_bit_cast(float, r2[0] & 0xFFFF0000u),
+                                   __builtin_bit_cast(float, r2[1] << 16), __builtin_bit_cast(float, r2[1] & 0xFFFF0000u)};
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(rv[r] - mu, rs * gam4[ni][r], acc[ni][mi][r] + bias4[ni][r]);
+            const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(stg + fr * T_EPI_ROW + (ni * 16 + 4 * fq) * 2) = u32x2{p0, p1};
+            // statistics of what the consumer will read: the rounded values
+            const float y0 = __builtin_bit_cast(float, p0 << 16), y1 = __builtin_bit_cast(float, p0 & 0xFFFF0000u);
+            const float y2 = __builtin_bit_cast(float, p1 << 16), y3 = __builtin_bit_cast(float, p1 & 0xFFFF0000u);
+            s1 += (y0 + y1) + (y2 + y3);
+            s2 = fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, fmaf(y3, y3, s2))));
+        }
+        sum1[mi] = s1;
+        sum2[mi] = s2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(stg + (j * 8 + prow) * T_EPI_ROW + c8 * 2);
+            bf16_t* dst = cp + (size_t)(mi * 16 + j * 8) * crs;
+            if (a.nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+            else *reinterpret_cast<u32x4*>(dst) = o;
+        }
+    }
+    // row sums: over this lane's 16 columns (above), the 4 k-groups of the wave (lanes fr + 16 fq), then the 4 waves of the row
+    // half through LDS -- a fixed order, so the statistics (and everything downstream) are reproducible bit for bit
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        sum1[mi] += __shfl_xor(sum1[mi], 16, 64);
+        sum2[mi] += __shfl_xor(sum2[mi], 16, 64);
+        sum1[mi] += __shfl_xor(sum1[mi], 32, 64);
+        sum2[mi] += __shfl_xor(sum2[mi], 32, 64);
+    }
+    float* part = reinterpret_cast<float*>(smem + w * 16384);  // this wave's residual slice is dead: [128 rows][2]
+    if (fq == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) *reinterpret_cast<f32x2_t*>(part + (mi * 16 + fr) * 2) = f32x2_t{sum1[mi], sum2[mi]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // raw barrier: __syncthreads() would also wait for the C stores
+    if (wn == 0) {  // waves 0 and 4: rows 2 ln, 2 ln + 1 of their half, summed over the four column blocks in wave order
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t += *reinterpret_cast<const f32x4*>(smem + (wm * 4 + v) * 16384 + ln * 16);
+        float* out = a.stats_out + ((size_t)(n0 / T_BN) * a.M + m0 + wm * 128) * 2 + ln * 4;
+        *reinterpret_cast<f32x4*>(out) = t;
+    }
+}
+
 // diagnostic time stamps (100 MHz wall clock): slot 0 = HW_ID, 1 = XCC_ID, 2.. = stamps
 static __device__ __forceinline__ void gemm256_stamp(const GemmArgs& a, int tile, int slot) {
     if (a.trace && threadIdx.x == 0) a.trace[(size_t)tile * 8 + slot] = (unsigned long long)wall_clock64();
@@ -228,12 +418,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // DBG bits: 1 no in-loop DMA, 2 no MFMA, 4 no epilogue, 16 no fragment reads (ablations, outputs meaningless);
-    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0) | (DBG & (32 | 64));
+    constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0);
     const int lda = a.ablock ? 64 : a.lda;
     const size_t a_kstep = a.ablock ? (size_t)a.M * 64 : (size_t)G_BK;
     if (EPI == EPI_BIAS_RES && !(DBG & 31))
         gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
                                   ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
+    else if (EPI == EPI_RESLN_STATS)
+        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
+                                  ResLnTailHook{ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
+                                                a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
+    else if (EPI == EPI_LNA_BIAS || EPI == EPI_LNA_GELU)
+        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
+                                  LnaTailHook{a.stats_in + (size_t)(m0 + (w >> 2) * 128) * 2, (size_t)a.M * 2, a.stat_slots, w, lane, smem}, a_kstep);
     else
         gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane, NoTailHook{}, a_kstep);
     gemm256_stamp(a, blockIdx.x, 3);
@@ -246,7 +443,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
         if (sink == 12345.678f) a.C[0] = 1;
         return;
     }
-    gemm256_epilogue<EPI>(a, m0, n0, smem, w, lane, acc);
+    if (EPI == EPI_RESLN_STATS) gemm256_epilogue_resln(a, m0, n0, smem, w, lane, acc);
+    else if (EPI == EPI_LNA_BIAS || EPI == EPI_LNA_GELU) gemm256_epilogue_lna<EPI>(a, m0, n0, smem, w, lane, acc);
+    else gemm256_epilogue<EPI>(a, m0, n0, smem, w, lane, acc);
     if (a.trace) {
         gemm256_stamp(a, blockIdx.x, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,9 +579,35 @@ static void launch256_epi(int epi, const GemmArgs& a, dim3 grid, dim3 block, hip
     else launch256<EPI_BIAS, DBG>(a, grid, block, s);
 }
 
+// LayerNorm-folded GEMMs of the batch pipeline (sc_encoder.cpp): M, N multiples of 256, K a multiple of 256 for EPI_LNA_* (the
+// statistics come in one slot per 256 columns of A).  epi = EPI_LNA_BIAS / EPI_LNA_GELU: bias = c2; EPI_RESLN_STATS: bias = b + beta.
+bool sc_gemm_ln_supported(int M, int N, int K) { return M > 0 && (M % T_BM) == 0 && (N % T_BN) == 0 && (K % 256) == 0; }
+void sc_launch_gemm_bf16_ln(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C, int ldc, int M,
+                            int N, int K, hipStream_t s, const float* c1, const float* stats_in, float* fin, const float* gam, float* stats_out, float eps) {
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
+    a.cblock = ldc == SC_LDC_BLOCKED64 ? 1 : 0;
+    a.ablock = lda == SC_LDC_BLOCKED64 ? 1 : 0;
+    static const char* env_order = getenv("SC_GEMM_ORDER");
+    a.order = env_order ? atoi(env_order) : ((size_t)N * (size_t)K * 2 <= ((size_t)8 << 20) ? 0 : 16);
+    a.trace = nullptr;
+    { static const char* env_nt = getenv("SC_GEMM_NT"); a.nt = env_nt ? atoi(env_nt) : ((size_t)M * (size_t)N * 2 >= ((size_t)64 << 20)); }
+    a.tiles_n = N / T_BN;
+    a.ntiles = (M / T_BM) * a.tiles_n;
+    a.splitk = 1;
+    a.partial = nullptr;
+    a.c1 = c1; a.stats_in = stats_in; a.stat_slots = K / 256; a.fin = fin; a.gam = gam; a.stats_out = stats_out; a.ln_eps = eps;
+    dim3 grid((unsigned)a.ntiles), block(512);
+    if (epi == EPI_LNA_BIAS) launch256<EPI_LNA_BIAS, 0>(a, grid, block, s);
+    else if (epi == EPI_LNA_GELU) launch256<EPI_LNA_GELU, 0>(a, grid, block, s);
+    else launch256<EPI_RESLN_STATS, 0>(a, grid, block, s);
+}
+
 void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C,
                          int ldc, int M, int N, int K, hipStream_t s, void* splitk_scratch, size_t splitk_scratch_bytes) {
     GemmArgs a;
+    a.c1 = nullptr; a.stats_in = nullptr; a.stat_slots = 0; a.fin = nullptr; a.gam = nullptr; a.stats_out = nullptr; a.ln_eps = 0.f;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.C = (bf16_t*)C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldc = ldc;
     a.cblock = ldc == SC_LDC_BLOCKED64 ? 1 : 0;
@@ -430,10 +655,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
             case 21: launch256<EPI_BIAS, 21>(a, grid, block, s); return;
             default: break;
         }
-        static const int var = getenv("SC_GEMM_VAR") ? atoi(getenv("SC_GEMM_VAR")) : 0;  // same-box A/B variants (gemm_tile.h)
-        if (var == 32) launch256_epi<32>(epi, a, grid, block, s);
-        else if (var == 64) launch256_epi<64>(epi, a, grid, block, s);
-        else launch256_epi<0>(epi, a, grid, block, s);
+        launch256_epi<0>(epi, a, grid, block, s);
         return;
     }
     a.tiles_n = N / G_BN;

@@ -211,8 +211,9 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 // a_kstep: elements from one K-tile of A to the next -- 64 for row-major A[M][lda]; M * 64 (with lda = 64) when A is stored in
 // 64-column blocks [K / 64][M][64], as the producing GEMM's blocked output layout writes it (gemm_bf16.hip c_index).
 // DBG (diagnostic builds only): bit 0 = skip the in-loop LDS-DMA, bit 1 = skip the MFMAs, bit 2 = skip the fragment reads
-// (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).  A/B variants with valid results
-// (SC_GEMM_VAR): 32 = s_setprio(1) around the MFMA blocks, 64 = the A operand's in-loop LDS-DMA with the nt cache policy.
+// (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).  Two variants with valid results were
+// A/B-tested on one box and dropped (gpurun_out/r2e: 20.8k -> 20.1k chunks/s each): s_setprio(1) around the MFMA blocks, and the
+// A operand's in-loop LDS-DMA with the nt cache policy.
 // tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
 // reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
 // tile, gemm_bf16.hip) and have it land under those MFMAs.
@@ -255,23 +256,19 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
         char* cur = smem + (kt & 1) * (2 * T_TILE_BYTES);
         char* nxt = smem + ((kt + 1) & 1) * (2 * T_TILE_BYTES);
         if (!(DBG & 4)) read_frags256(cur, cur + T_TILE_BYTES, wm, wn, fr, fq, 1, f1);
-        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
         if (!(DBG & 2)) mfma_frags256<I8>(f0, acc);
         else asm volatile("" ::"v"(f0.wf[0]), "v"(f0.af[0]), "v"(f0.wf[3]), "v"(f0.af[7]));
-        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my LDS-DMA of tile kt+1 (issued one K-tile ago)
         __syncthreads();                                   // + every wave's reads of `cur` are complete
         if (!STAGE && !NEXT) tail();
         if (STAGE && !(DBG & 1)) {
-            stage_tile256<(DBG & 64) ? 2 : 0>(A + (size_t)(kt + 2) * a_kstep, lda, m0, 0, cur, w, lane);
+            stage_tile256(A + (size_t)(kt + 2) * a_kstep, lda, m0, 0, cur, w, lane);
             stage_tile256(W, ldw, n0, (kt + 2) * G_BK, cur + T_TILE_BYTES, w, lane);
         }
         if (NEXT && !(DBG & 4)) read_frags256(nxt, nxt + T_TILE_BYTES, wm, wn, fr, fq, 0, f0);
-        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
         if (!(DBG & 2)) mfma_frags256<I8>(f1, acc);
         else asm volatile("" ::"v"(f1.wf[0]), "v"(f1.af[0]), "v"(f1.wf[3]), "v"(f1.af[7]));
-        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
         if (STAGE && !(DBG & 1) && NEXT && !(DBG & 2) && !(DBG & 4)) {
             // spread the 8 LDS-DMA issues (each ~100 issue cycles with its address arithmetic) and the 12 fragment reads
             // between the 32 MFMAs instead of bursting them right after the barrier, where both waves of a SIMD would

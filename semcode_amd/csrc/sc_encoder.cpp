@@ -29,6 +29,17 @@ void sc_launch_layernorm(const void* in, int tokens, int H, const float* g, cons
 bool sc_attention_supported(int S, int H, int heads);
 void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s, int blocked = 0);
 void sc_launch_geglu(const void* h, int64_t tokens, int F, void* out, hipStream_t s);
+// LayerNorm-folded batch pipeline (gemm_bf16.hip EPI_LNA_* / EPI_RESLN_STATS, encoder_ops.hip)
+bool sc_gemm_ln_supported(int M, int N, int K);
+void sc_launch_gemm_bf16_ln(int epi, const void* A, int lda, const void* W, int ldw, const float* bias, const void* R, int ldr, void* C, int ldc, int M,
+                            int N, int K, hipStream_t s, const float* c1, const float* stats_in, float* fin, const float* gam, float* stats_out, float eps);
+void sc_launch_embed_raw(const int32_t* ids, int tokens, int tokens_pad, int S, int H, int vocab, int max_pos, const float* wemb, const float* pemb,
+                         const float* temb, void* out, float* stats, int slots, hipStream_t s);
+void sc_launch_fold_ln_weights(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, void* Wf, float* c1, float* c2,
+                               hipStream_t s);
+void sc_launch_add_vectors(const float* a, const float* b, float* out, int n, hipStream_t s);
+void sc_launch_mean_pool_ln(const void* y, const float* stats, int slots, int tokens_pad, const float* gamma, const float* beta, float eps,
+                            const int32_t* lens, int B, int S, int H, float* out, hipStream_t s);
 void sc_launch_mean_pool(const void* x, const int32_t* lens, int B, int S, int H, int normalize, float* out, hipStream_t s);
 void sc_launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
 void sc_launch_synth_scaled(float* out, int64_t n, uint64_t seed, float scale, float offset, hipStream_t s);
@@ -39,7 +50,7 @@ void sc_gemm_set_order(int v);
 void sc_gemm_set_trace(unsigned long long* dev);
 void sc_gemm_force_tile128(bool on);
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_LNA_BIAS = 3, EPI_LNA_GELU = 4, EPI_RESLN_STATS = 5 };
 
 struct LayerW {
     void* wqkv;  // bf16 [3H, H]
@@ -52,6 +63,12 @@ struct LayerW {
     void* w2;    // bf16 [H, F]
     float* b2;
     float *ln2g, *ln2b;
+    // LayerNorm-folded copies for the batch pipeline (forward_folded): the LayerNorm in FRONT of a GEMM lives in its weights --
+    // Wqkv' = Wqkv diag(gamma of the previous LayerNorm), W1' = W1 diag(ln1 gamma) -- and in two vectors per GEMM (gemm_bf16.hip)
+    void *wqkv_f = nullptr, *w1_f = nullptr;
+    float *c1q = nullptr, *c2q = nullptr, *c1f = nullptr, *c2f = nullptr;
+    const float* g_prev = nullptr;  // gamma of the LayerNorm that produces this layer's input (embedding LN or the previous layer's ln2)
+    float *bb_o = nullptr, *bb_2 = nullptr;  // bo + beta_prev, b2 + ln1 beta: the residual epilogues add the normalised residual's beta with the bias
 };
 
 struct sc_encoder {
@@ -70,6 +87,10 @@ struct sc_encoder {
     int32_t* lens = nullptr;
     float* pooled = nullptr;
     int64_t ws_batch = 0;
+    float *stat_a = nullptr, *stat_b = nullptr;  // [slots][ws_tokens][2] partial row sums of the two pre-LayerNorm tensors (folded pipeline)
+    float *fin_a = nullptr, *fin_b = nullptr;    // [ws_tokens][2] their finalised (mu, rs)
+    bool foldable = false;                       // shapes allow the folded pipeline (256-tile GEMMs, K % 256 == 0)
+    int path = 0;                                // sc_encoder_set_path: 0 auto, 1 batch pipeline always, 2 small-batch pipeline always
     void* splitk = nullptr;  // f32 partial products of the split-K GEMMs (batches of <= 1024 tokens), allocated on first use
     static constexpr size_t SPLITK_BYTES = 64u << 20;
     // pinned host staging for the asynchronous embed -> index path: ids | lens | rows of one batch per slot
@@ -149,12 +170,19 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
     const size_t o_wemb = reserve((size_t)cfg->vocab * H * 4), o_pemb = reserve(alibi ? 16 : (size_t)cfg->max_pos * H * 4),
                  o_slopes = reserve((size_t)cfg->heads * 4),
                  o_temb = reserve((size_t)cfg->type_vocab * H * 4), o_eg = reserve(H * 4), o_eb = reserve(H * 4);
-    struct LO { size_t wqkv, bqkv, wo, bo, l1g, l1b, w1, b1, w2, b2, l2g, l2b; };
+    struct LO { size_t wqkv, bqkv, wo, bo, l1g, l1b, w1, b1, w2, b2, l2g, l2b, wqkv_f, c1q, c2q, w1_f, c1f, c2f, bb_o, bb_2; };
     std::vector<LO> lo(L);
+    // the LayerNorm-folded batch pipeline needs every GEMM on the 256 x 256 tile and the statistics in whole 256-column slots
+    e->foldable = (H % 256) == 0 && (F % 256) == 0 && (F1 % 256) == 0 && ((3 * H) % 256) == 0;
     for (int64_t l = 0; l < L; ++l) {
         lo[l].wqkv = reserve(3 * H * H * 2); lo[l].bqkv = reserve(3 * H * 4); lo[l].wo = reserve(H * H * 2); lo[l].bo = reserve(H * 4);
         lo[l].l1g = reserve(H * 4); lo[l].l1b = reserve(H * 4); lo[l].w1 = reserve(F1 * H * 2); lo[l].b1 = reserve(F1 * 4);
         lo[l].w2 = reserve(H * F * 2); lo[l].b2 = reserve(H * 4); lo[l].l2g = reserve(H * 4); lo[l].l2b = reserve(H * 4);
+        if (e->foldable) {
+            lo[l].wqkv_f = reserve(3 * H * H * 2); lo[l].c1q = reserve(3 * H * 4); lo[l].c2q = reserve(3 * H * 4);
+            lo[l].w1_f = reserve(F1 * H * 2); lo[l].c1f = reserve(F1 * 4); lo[l].c2f = reserve(F1 * 4);
+            lo[l].bb_o = reserve(H * 4); lo[l].bb_2 = reserve(H * 4);
+        }
     }
     he = hipMalloc((void**)&e->params, total);
     if (he != hipSuccess) return fail(sc_fail(SC_ERR_NOMEM, "hipMalloc parameters (%zu B) failed: %s", total, hipGetErrorString(he)));
@@ -212,8 +240,10 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
         // blob order: Wq bq Wk bk Wv bv Wo bo ln1g ln1b W1 b1 W2 b2 ln2g ln2b ; device: Wqkv = [Wq; Wk; Wv]
         char* wqkv = e->params + lo[l].wqkv;
         float* bqkv = (float*)(e->params + lo[l].bqkv);
+        const float* wqkv_f32[3];
         for (int p = 0; p < 3; ++p) {
             const float* wp = take(H * H);
+            wqkv_f32[p] = wp;
             sc_launch_f32_to_bf16(wp, wqkv + (size_t)p * H * H * 2, H * H, s);
             const float* bp = take(H);
             if (weights_blob) hipMemcpyAsync(bqkv + p * H, bp, H * 4, hipMemcpyDeviceToDevice, s);
@@ -225,12 +255,29 @@ extern "C" sc_status sc_encoder_create(sc_runtime* rt, const sc_encoder_cfg* cfg
         w.bo = put_f32(lo[l].bo, take(H), H, 2);
         w.ln1g = put_f32(lo[l].l1g, take(H), H, 1);
         w.ln1b = put_f32(lo[l].l1b, take(H), H, 2);
-        w.w1 = put_bf16(lo[l].w1, take(F1 * H), F1 * H);
+        const float* w1_f32 = take(F1 * H);
+        w.w1 = put_bf16(lo[l].w1, w1_f32, F1 * H);
         w.b1 = put_f32(lo[l].b1, take(F1), F1, 2);
         w.w2 = put_bf16(lo[l].w2, take(H * F), H * F);
         w.b2 = put_f32(lo[l].b2, take(H), H, 2);
         w.ln2g = put_f32(lo[l].l2g, take(H), H, 1);
         w.ln2b = put_f32(lo[l].l2b, take(H), H, 2);
+        if (e->foldable) {
+            // the LayerNorm in front of this layer: the embeddings' for layer 0, else the previous layer's second one
+            const float* gp = l == 0 ? e->embg : e->layers[l - 1].ln2g;
+            const float* bp = l == 0 ? e->embb : e->layers[l - 1].ln2b;
+            w.g_prev = gp;
+            w.wqkv_f = e->params + lo[l].wqkv_f;
+            w.c1q = (float*)(e->params + lo[l].c1q); w.c2q = (float*)(e->params + lo[l].c2q);
+            for (int p = 0; p < 3; ++p)  // Wq, Wk, Wv are separate tensors of the blob
+                sc_launch_fold_ln_weights(wqkv_f32[p], gp, bp, bqkv + p * H, (int)H, (int)H, (char*)w.wqkv_f + (size_t)p * H * H * 2, w.c1q + p * H, w.c2q + p * H, s);
+            w.w1_f = e->params + lo[l].w1_f;
+            w.c1f = (float*)(e->params + lo[l].c1f); w.c2f = (float*)(e->params + lo[l].c2f);
+            sc_launch_fold_ln_weights(w1_f32, w.ln1g, w.ln1b, w.b1, (int)F1, (int)H, w.w1_f, w.c1f, w.c2f, s);
+            w.bb_o = (float*)(e->params + lo[l].bb_o); w.bb_2 = (float*)(e->params + lo[l].bb_2);
+            sc_launch_add_vectors(w.bo, bp, w.bb_o, (int)H, s);
+            sc_launch_add_vectors(w.b2, w.ln1b, w.bb_2, (int)H, s);
+        }
     }
     he = hipStreamSynchronize(s);
     if (he == hipSuccess) he = hipGetLastError();
@@ -272,13 +319,83 @@ static sc_status ensure_ws(sc_encoder* e, int64_t B, int64_t S) {
     const size_t ox = reserve(tokens * H * 2), ox1 = reserve(tokens * H * 2), oy = reserve(tokens * H * 2), oqkv = reserve(tokens * 3 * H * 2),
                  octx = reserve(tokens * H * 2), ohm = reserve(tokens * F1 * 2), ohg = reserve(e->cfg.ffn_type == 1 ? tokens * F * 2 : 16),
                  oids = reserve(tokens * 4), olens = reserve(nb * 4), opool = reserve(nb * H * 4);
+    const size_t slots = (size_t)H / 256;
+    const size_t osa = reserve(e->foldable ? slots * tokens * 8 : 16), osb = reserve(e->foldable ? slots * tokens * 8 : 16),
+                 ofa = reserve(e->foldable ? tokens * 8 : 16), ofb = reserve(e->foldable ? tokens * 8 : 16);
     hipError_t he = hipMalloc((void**)&e->ws, total);
     if (he != hipSuccess) return sc_fail(SC_ERR_NOMEM, "hipMalloc encoder workspace (%zu B) failed: %s", total, hipGetErrorString(he));
     SC_HIP(hipMemsetAsync(e->ws, 0, total, e->rt->stream));  // padded rows must hold finite values
     e->x = e->ws + ox; e->x1 = e->ws + ox1; e->y = e->ws + oy; e->qkv = e->ws + oqkv; e->ctx = e->ws + octx; e->hm = e->ws + ohm; e->hg = e->ws + ohg;
     e->ids = (int32_t*)(e->ws + oids); e->lens = (int32_t*)(e->ws + olens); e->pooled = (float*)(e->ws + opool);
+    e->stat_a = (float*)(e->ws + osa); e->stat_b = (float*)(e->ws + osb); e->fin_a = (float*)(e->ws + ofa); e->fin_b = (float*)(e->ws + ofb);
     e->ws_tokens = tokens;
     e->ws_batch = nb;
+    return SC_OK;
+}
+
+// The batch pipeline with every LayerNorm folded into its neighbours (no layernorm_kernel launch, no LayerNorm round trip
+// through HBM: 24 x 33 us and 24 x 200 MB per step at 256 x 256 tokens).  Activations between layers are the PRE-LayerNorm
+// tensors (raw bf16 rows) together with their row statistics:
+//   embed_raw                     -> x  (raw) + stat_b            x = word + position + type embeddings
+//   per layer, LN_p = the LayerNorm that belongs in front of it (embeddings' / previous layer's second):
+//     QKV   = LN_p(x) Wqkv^T + b   as  rs (x Wqkv'^T - mu c1) + c2            EPI_LNA_BIAS   (stat_b -> fin_b)
+//     y     = ctx Wo^T + bo + LN_p(x)    residual normalised on the fly, row sums of y out   EPI_RESLN_STATS (fin_b -> stat_a)
+//     hm    = gelu(LN_1(y) W1^T + b1)    folded the same way                                 EPI_LNA_GELU   (stat_a -> fin_a)
+//     x     = hm W2^T + b2 + LN_1(y)                                                         EPI_RESLN_STATS (fin_a -> stat_b)
+//   pooled = masked mean of LN_2(x) of the last layer, normalised on the fly (mean_pool_ln)
+// Statistics are taken of the bf16-ROUNDED rows, i.e. of exactly what the consumer reads; all reductions run in a fixed order.
+static sc_status forward_folded_locked(sc_encoder* e, const int32_t* ids_dev, const int32_t* lens_dev, int32_t B, int32_t S, float* out_dev) {
+    const sc_encoder_cfg& c = e->cfg;
+    sc_runtime* rt = e->rt;
+    hipStream_t s = rt->stream;
+    const int H = c.hidden, F = c.ffn;
+    const int tokens = B * S;
+    const int M = (tokens + 255) / 256 * 256;
+    const int slots = H / 256;
+    // statistics buffers are laid out for ws_tokens rows; this call uses the first M rows of every slot: slot stride must be M, so
+    // they are addressed as [slots][M][2] inside the (larger or equal) allocation
+    static const char* env_fb = getenv("SC_FFN_BLOCKED");
+    const bool ffn_blocked = c.ffn_type != 1 && !(env_fb && env_fb[0] == '0');
+    sc_launch_embed_raw(ids_dev, tokens, M, S, H, c.vocab, c.max_pos, e->wemb, e->pemb, e->temb, e->x, e->stat_b, slots, s);
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerW& w = e->layers[l];
+        hipEvent_t g0, g1;
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16_ln(EPI_LNA_BIAS, e->x, H, w.wqkv_f, H, w.c2q, nullptr, 0, e->qkv, SC_LDC_BLOCKED64, M, 3 * H, H, s, w.c1q, e->stat_b, e->fin_b, nullptr,
+                               nullptr, c.ln_eps);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        hipEvent_t a0, a1;
+        sc_prof_begin(rt, SC_PROF_ATTN, &a0, &a1);
+        sc_launch_attention(e->qkv, lens_dev, B, S, H, e->slopes, e->ctx, s, M);
+        sc_prof_end(rt, SC_PROF_ATTN, a0, a1);
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16_ln(EPI_RESLN_STATS, e->ctx, H, w.wo, H, w.bb_o, e->x, H, e->y, H, M, H, H, s, nullptr, nullptr, e->fin_b, w.g_prev, e->stat_a, c.ln_eps);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        const void* ffn_in = e->hm;
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        if (c.ffn_type == 1)
+            sc_launch_gemm_bf16_ln(EPI_LNA_BIAS, e->y, H, w.w1_f, H, w.c2f, nullptr, 0, e->hm, 2 * F, M, 2 * F, H, s, w.c1f, e->stat_a, e->fin_a, nullptr, nullptr, c.ln_eps);
+        else
+            sc_launch_gemm_bf16_ln(EPI_LNA_GELU, e->y, H, w.w1_f, H, w.c2f, nullptr, 0, e->hm, ffn_blocked ? SC_LDC_BLOCKED64 : F, M, F, H, s, w.c1f, e->stat_a,
+                                   e->fin_a, nullptr, nullptr, c.ln_eps);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+        if (c.ffn_type == 1) {
+            sc_launch_geglu(e->hm, M, F, e->hg, s);
+            ffn_in = e->hg;
+        }
+        sc_prof_begin(rt, SC_PROF_GEMM, &g0, &g1);
+        sc_launch_gemm_bf16_ln(EPI_RESLN_STATS, ffn_in, (ffn_blocked && c.ffn_type != 1) ? SC_LDC_BLOCKED64 : F, w.w2, F, w.bb_2, e->y, H, e->x, H, M, H, F, s, nullptr,
+                               nullptr, e->fin_a, w.ln1g, e->stat_b, c.ln_eps);
+        sc_prof_end(rt, SC_PROF_GEMM, g0, g1);
+    }
+    const LayerW& last = e->layers[c.layers - 1];
+    if (c.normalize) {  // L2-normalised output: the plain pooling kernel does it; give it the normalised rows
+        sc_launch_layernorm(e->x, tokens, H, last.ln2g, last.ln2b, c.ln_eps, e->x1, s);
+        sc_launch_mean_pool(e->x1, lens_dev, B, S, H, c.normalize, out_dev, s);
+    } else {
+        sc_launch_mean_pool_ln(e->x, e->stat_b, slots, M, last.ln2g, last.ln2b, c.ln_eps, lens_dev, B, S, H, out_dev, s);
+    }
+    SC_HIP(hipGetLastError());
     return SC_OK;
 }
 
@@ -290,8 +407,12 @@ static sc_status forward_locked(sc_encoder* e, const int32_t* ids_dev, const int
     const int H = c.hidden, F = c.ffn;
     const int tokens = B * S;
     const int M = (tokens + 255) / 256 * 256;
+    // batches beyond 1024 token rows (or sc_encoder_set_path 1) take the LayerNorm-folded pipeline where the model's shapes allow it
+    static const char* env_fold = getenv("SC_ENC_FOLD");  // SC_ENC_FOLD=0: same-box A/B against the stand-alone LayerNorm kernels
+    if (e->foldable && e->path != 2 && (M > 1024 || e->path == 1) && !(env_fold && env_fold[0] == '0'))
+        return forward_folded_locked(e, ids_dev, lens_dev, B, S, out_dev);
     void* sk = nullptr;
-    if (M <= 1024) {  // a query or a few chunks: too few tiles for the chip, split K (gemm_bf16.hip)
+    if (M <= 1024 && e->path != 1) {  // a query or a few chunks: too few tiles for the chip, split K (gemm_bf16.hip)
         if (!e->splitk) SC_HIP(hipMalloc(&e->splitk, sc_encoder::SPLITK_BYTES));
         sk = e->splitk;
     }
@@ -467,6 +588,13 @@ extern "C" sc_status sc_encoder_wait(sc_encoder* e) {
         if (st && !first) first = st;
     }
     return first;
+}
+
+extern "C" sc_status sc_encoder_set_path(sc_encoder* e, int32_t path) {
+    if (!e || path < 0 || path > 2) return sc_fail(SC_ERR_INVALID, "sc_encoder_set_path: path must be 0 (auto), 1 (batch pipeline) or 2 (small-batch pipeline)");
+    std::lock_guard<std::mutex> g(e->mu);
+    e->path = path;
+    return SC_OK;
 }
 
 extern "C" sc_status sc_encoder_info(sc_encoder* e, sc_encoder_cfg* cfg_out) {

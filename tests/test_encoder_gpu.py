@@ -108,26 +108,58 @@ def check_pooled(got, want):
     assert np.abs(got - want).max() <= 2e-2, np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("path", ["small", "batch"])  # split-K + LayerNorm kernels | 256-tile GEMMs with every LayerNorm folded in
 @pytest.mark.parametrize("case", ["tiny", "base1", "base12"])
-def test_encoder_matches_transformers_golden(rt, enc_golden, case):
+def test_encoder_matches_transformers_golden(rt, enc_golden, case, path):
     data, meta = enc_golden
     m = meta[case]
-    blob = bo.make_blob(m["cfg"], m["seed"], m["style"])
+    blob = bo.make_blob(m["cfg"], m["seed"], m["style"])  # style "test": LayerNorm gamma / beta and all biases are non-trivial
     enc = _native.Encoder(rt, m["cfg"], weights=blob)
+    enc.set_path(path)
     got = enc.embed_ids(data[f"{case}_ids"], data[f"{case}_lens"])
     check_pooled(got, data[f"{case}_pooled"])
     enc.close()
 
 
-def test_encoder_device_synthetic_weights_match_oracle_rule(rt, enc_golden):
+@pytest.mark.parametrize("path", ["small", "batch"])
+def test_encoder_device_synthetic_weights_match_oracle_rule(rt, enc_golden, path):
     # no blob: the library builds the benchmark weights on device; the golden output was produced by
     # transformers with the same rule restated in oracle.bert_oracle.make_blob(style="bench")
     data, meta = enc_golden
     m = meta["base12_bench_weights"]
     enc = _native.Encoder(rt, m["cfg"], weights=None, synth_seed=m["seed"])
+    enc.set_path(path)
     got = enc.embed_ids(data["base12_bench_weights_ids"], data["base12_bench_weights_lens"])
     check_pooled(got, data["base12_bench_weights_pooled"])
     enc.close()
+
+
+def test_layernorm_folded_pipeline_equals_the_layernorm_kernels(rt):
+    """The two pipelines on the same ragged batch, BERT-base shape with non-trivial LayerNorm parameters and biases (make_blob
+    style "test"), 3 layers: the folded one (statistics from the producing epilogue, normalisation inside the consuming GEMM)
+    must agree with the stand-alone LayerNorm kernels to bf16 noise, and with the float64 restatement to the usual bar; a
+    normalised-output encoder takes the folded pipeline's other pooling branch."""
+    cfg = dict(bo.BERT_BASE, layers=3, vocab=2000, max_pos=128)
+    blob = bo.make_blob(cfg, 5, "test")
+    rng = np.random.default_rng(6)
+    ids = rng.integers(1, 2000, size=(9, 128)).astype(np.int32)  # 1 152 token rows -> 1 280 padded
+    lens = np.array([128, 1, 77, 128, 33, 100, 2, 128, 64], np.int32)
+    want = bo.forward(cfg, blob, ids, lens)
+    for normalize in (False, True):
+        enc = _native.Encoder(rt, cfg, weights=blob, normalize=normalize)
+        ref = want / np.linalg.norm(want, axis=1, keepdims=True) if normalize else want
+        out = {}
+        for path in ("small", "batch"):
+            enc.set_path(path)
+            out[path] = enc.embed_ids(ids, lens)
+            cos = (out[path] * ref).sum(1) / (np.linalg.norm(out[path], axis=1) * np.linalg.norm(ref, axis=1))
+            assert cos.min() >= 0.999, (path, normalize, cos)
+        scale = float(np.abs(ref).max())
+        assert np.abs(out["small"] - out["batch"]).max() <= 3e-2 * scale, np.abs(out["small"] - out["batch"]).max()
+        enc.set_path("batch")
+        perm = rng.permutation(9)
+        assert np.array_equal(enc.embed_ids(ids[perm], lens[perm]), out["batch"][perm])  # fixed reduction orders: bit-reproducible
+        enc.close()
 
 
 def test_encoder_batch_and_padding_invariance(rt):
