@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+MFMA_I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md, matrix-core table: i8 16x16x64 = the cycles of bf16 16x16x32 at twice the K
 
 
 def parse():
@@ -251,6 +252,7 @@ def bench_scan(ctx, args) -> dict:
     rt.set_profiling(False)
     st = ix.last_search_stats()
     path, unc = st["path"], st["uncertified"]
+    coarse_bits, handed = st.get("coarse_bits", 16), st.get("handed_to_bf16", 0)
     groups = (Q + 15) // 16  # exact path: one corpus pass per 16 queries
 
     # Batch-size sweep: the scan is HBM-bound for small batches (exact f32 kernel, one corpus pass per <= 16 queries)
@@ -287,19 +289,25 @@ def bench_scan(ctx, args) -> dict:
     ld = (dim + 63) // 64 * 64
     step_s = dt / args.steps
     if path == "batched":
-        # dominant kernel = scan_coarse_kernel (bf16 MFMA GEMM + filter), several phase launches per step
-        qpad = (Q + 127) // 128 * 128
+        # dominant kernel = scan_coarse256_kernel (MFMA GEMM of the coarse shadow against the query batch + threshold filter), several
+        # phase launches per step; int8 stage: v_mfma_i32_16x16x64_i8 on the int8 shadow (peak 2x the bf16 rate), else bf16
+        i8 = coarse_bits == 8
+        qpad = (Q + 255) // 256 * 256 if (i8 or Q > 128) else 128
         flops = 2.0 * rows * ld * qpad * args.steps
         achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_n else None
-        roof = {"bound": "mfma", "kernel": "scan_coarse_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS if achieved else None,
+        peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
+        roof = {"bound": "mfma", "kernel": "scan_coarse256_kernel<int8>" if i8 else "scan_coarse256_kernel<bf16>", "achieved": achieved, "peak": peak,
+                "unit": "TOP/s" if i8 else "TFLOP/s", "frac": achieved / peak if achieved else None,
+                "frac_of_bf16_peak": achieved / MFMA_BF16_PEAK_TFLOPS if achieved else None,
                 "traffic": coarse_traffic(rows, Q) if dim == 768 else None,
-                "traffic_note": f"HBM-side bytes per step over the phase launches (bf16 shadow = rows*ld*2), {(pmc_traffic() or {}).get('_file')}",
+                "traffic_note": f"HBM-side bytes per step over the phase launches (coarse shadow = rows*ld*{1 if i8 else 2} B), {(pmc_traffic() or {}).get('_file')}",
+                "coarse_stage": "int8 (per-row scale, 512 candidates/query)" if i8 else "bf16 (128 candidates/query)", "queries_handed_to_bf16_stage": handed,
                 "algorithmic_flops_per_step": flops / args.steps, "kernel_ms_per_step": scan_ms / args.steps, "launches": scan_n,
                 "select_ms_per_step": merge_ms / args.steps,
                 "hbm_view": {"algorithmic_bytes_per_step": alg_bytes, "achieved_gbs": alg_bytes / step_s / 1e9,
                              "frac_of_8TBs": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                             "note": "at Q=1024 the binding roof is bf16 MFMA (6.3 ms at peak vs 3.8 ms to stream the 15.4 GB bf16 shadow)"}}
+                             "note": "algorithmic bytes = the f32 shard once per batch (SURVEY 8d); at Q=1024 the binding roof is the matrix pipe: "
+                                     "2*rows*dim*Q = 1.57e13 ops = 3.1 ms at the int8 peak / 6.3 ms at the bf16 peak, vs 1.0 / 1.9 ms to stream the 7.7 / 15.4 GB shadow"}}
     else:
         kern_ms = scan_ms / max(1, scan_n)
         achieved = alg_bytes * groups / (kern_ms * 1e-3) / 1e9 if scan_n else None
@@ -314,7 +322,7 @@ def bench_scan(ctx, args) -> dict:
         "ms_per_step": 1e3 * step_s,
         "rows_scanned_per_s": Q * args.steps / dt * rows * world,
         "workload": f"brute-force {args.metric_type} top-{k}, {rows} x {dim} f32 rows per GPU ({rows * world} total), batch-{Q} queries",
-        "dtype": "bf16 coarse + f32 exact re-rank" if path == "batched" else "f32",
+        "dtype": (("int8" if coarse_bits == 8 else "bf16") + " coarse + f32 exact re-rank") if path == "batched" else "f32",
         "path": path, "uncertified_queries_last_step": unc,
         "roofline": roof,
     }

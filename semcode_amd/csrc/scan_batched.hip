@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 // lane queues its (rare) hits in registers so that the global atomics that allocate list slots are issued
 // back to back and their latency is paid once per tile, not once per hit.
 #define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256], qscale[256], xscale[256]} in LDS
-#define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 6 * 256 * 4 + 8 * 2048)  // + the per-wave hit lists of the epilogue (COARSE_LIST_BYTES)
+#define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 6 * 256 * 4)
 // per-tile staging of the workgroup's 256 query thresholds / norms and the tile's 256 row norms (visible to everyone after
 // the main loop's barriers)
 template <bool I8 = false>
@@ -292,14 +292,10 @@ static __device__ __forceinline__ void coarse256_coords(const CoarseArgs& a, int
     m0 = a.row0 + (int64_t)(g * G + r % rows_here) * T_BM;
     n0 = (r / rows_here) * T_BN;
 }
-// Epilogue.  Hits are rare per LANE (a few per wave and tile once the thresholds are tight) but not per wave: with 512 candidates
-// kept per query a quarter of the 4-score groups of a wave contain one.  So there is no wave-uniform branch around a block that
-// re-tests all four scores (that block cost ~1 200 cycles each time: 4.3 of the 11.3 ms of the int8 stage, gpurun_out/r2e_scan_i8.log):
-// every score gets ONE compare against a per-row bound (below), and only the lanes that pass run the precise test and park their
-// key in a per-wave list in LDS; the list is flushed to the per-query survivor lists once per tile, with the global atomics that
-// allocate the slots issued back to back.
-#define COARSE_LIST_CAP 160
-#define COARSE_LIST_BYTES 2048  // per wave: keys [CAP] u64 | local query [CAP] u32 | counter
+// Epilogue.  One compare per score against a per-row bound, a wave-uniform branch per group of 4 scores around the precise test.
+// A variant without that branch -- every lane that passes the bound runs the precise test under its own exec mask and parks
+// its key in a per-wave LDS list flushed once per tile -- was measured on the same box and lost (int8 stage 11.25 -> 12.28 ms,
+// bf16 15.05 -> 16.2 ms per step, gpurun_out/r2f_scan_*.log): the divergent bodies cost more than the uniform branch saves.
 template <int METRIC, bool I8 = false>
 static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
                                                           int lane) {
@@ -309,11 +305,6 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     const float* q_thr = q_tf + 256;
     const float* q_qn = q_tf + 512;
     const float* x_xn = q_tf + 768;  // |x|^2 of the tile's 256 corpus rows
-    char* wl = smem + COARSE_QLDS + 6 * 256 * 4 + w * COARSE_LIST_BYTES;
-    uint64_t* l_key = reinterpret_cast<uint64_t*>(wl);
-    unsigned* l_q = reinterpret_cast<unsigned*>(wl + COARSE_LIST_CAP * 8);
-    unsigned* l_cnt = reinterpret_cast<unsigned*>(wl + COARSE_LIST_CAP * 12);
-    if (lane == 0) *l_cnt = 0u;  // wave-private: LDS operations of one wave execute in order
     // acc[ni][mi][r] = <x[m0 + wm*128 + mi*16 + fr], q[n0 + wn*64 + ni*16 + 4*fq + r]>  (bf16 inputs)
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 tf[4], sq[4];  // sq: int8 stage only, the query scales of this lane's 16 columns
@@ -326,11 +317,14 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) tfmax = fmaxf(fmaxf(tfmax, fmaxf(tf[ni][0], tf[ni][1])), fmaxf(tf[ni][2], tf[ni][3]));
     const float sq0 = I8 ? sq[0][0] : 1.0f;  // the batch's common query scale
+    // hits of this lane: up to 4 queued (local query index, key); a 5th and later ones are flushed directly
+    int nh = 0;
+    int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
+    uint64_t hk0 = 0, hk1 = 0, hk2 = 0, hk3 = 0;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int rl = wm * 128 + mi * 16 + fr;
-        const int64_t row = m0 + rl;
-        const float xn = x_xn[rl];  // staged at kernel start
+        const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
         const float sx = I8 ? q_tf[1280 + rl] : 0.f;  // int8 stage: the integer dot is scaled by s_r s_q
         const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
@@ -345,51 +339,69 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         int Ti = 0;
         if (I8) Ti = !(Tlb == Tlb) ? (int)0x80000000 : Tlb <= -2.0e9f ? (int)0x80000000 : Tlb >= 2.0e9f ? 0x7FFFFFFF : (int)Tlb - 1;
         if (!I8 && !(Tlb == Tlb)) Tlb = -__builtin_inff();  // NaN (0 * inf on an all-zero row): let the precise test decide
-        if (row >= a.row1) { Ti = 0x7FFFFFFF; Tlb = __builtin_inff(); }  // padding rows of the last tile never pass
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
+            // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
+            bool g;
+            if (I8) {
+                const int a0 = __float_as_int(acc[ni][mi][0]), a1 = __float_as_int(acc[ni][mi][1]), a2 = __float_as_int(acc[ni][mi][2]),
+                          a3 = __float_as_int(acc[ni][mi][3]);
+                g = (a0 >= Ti) | (a1 >= Ti) | (a2 >= Ti) | (a3 >= Ti);
+            } else {
+                g = (acc[ni][mi][0] >= Tlb) | (acc[ni][mi][1] >= Tlb) | (acc[ni][mi][2] >= Tlb) | (acc[ni][mi][3] >= Tlb);
+            }
+            if (!__any(g)) continue;
+            f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float accv = acc[ni][mi][r];
-                const bool pre = I8 ? (__float_as_int(accv) >= Ti) : (accv >= Tlb);
-                if (pre) {  // divergent, rare per lane
-                    float t;
-                    if (I8) {
-                        const float av = (float)__float_as_int(accv) * ar;
-                        t = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
-                    } else {
-                        t = (METRIC == SC_METRIC_L2) ? fmaf(-2.0f, accv, xn) : (METRIC == SC_METRIC_COSINE) ? -accv * xs : -accv;
-                    }
-                    if (t <= tf[ni][r]) {
+                if (I8) {
+                    const float av = (float)__float_as_int(acc[ni][mi][r]) * ar;
+                    t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
+                } else {
+                    const float dot = acc[ni][mi][r];
+                    if (METRIC == SC_METRIC_L2) t[r] = fmaf(-2.0f, dot, xn);
+                    else if (METRIC == SC_METRIC_COSINE) t[r] = -dot * xs;
+                    else t[r] = -dot;
+                }
+            }
+            {
+                const int64_t row = m0 + rl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row < a.row1 && t[r] <= tf[ni][r]) {
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
+                        const float accv = acc[ni][mi][r];
                         const float dotv = I8 ? (float)__float_as_int(accv) * (sx * sq[ni][r]) : accv;
                         const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries
                             const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
-                            const unsigned lp = atomicAdd(l_cnt, 1u);
-                            if (lp < COARSE_LIST_CAP) {
-                                l_key[lp] = key;
-                                l_q[lp] = (unsigned)ql;
-                            } else {  // list full (the all-pass tiles of the first phases): straight to the global list
+                            if (nh == 0) { hq0 = ql; hk0 = key; }
+                            else if (nh == 1) { hq1 = ql; hk1 = key; }
+                            else if (nh == 2) { hq2 = ql; hk2 = key; }
+                            else if (nh == 3) { hq3 = ql; hk3 = key; }
+                            else {
                                 const unsigned pos = atomicAdd(a.count + n0 + ql, 1u);
                                 if (pos < (unsigned)a.cap) a.surv[(size_t)(n0 + ql) * a.cap + pos] = key;
                             }
+                            ++nh;
                         }
                     }
                 }
             }
         }
     }
-    // flush: one parked hit per lane and round, the slot-allocating atomics of a round issued together
-    unsigned nl = *l_cnt;
-    nl = nl < COARSE_LIST_CAP ? nl : COARSE_LIST_CAP;
-    for (unsigned i = lane; i < nl; i += 64) {
-        const uint64_t key = l_key[i];
-        const unsigned ql = l_q[i];
-        const unsigned pos = atomicAdd(a.count + n0 + ql, 1u);
-        if (pos < (unsigned)a.cap) a.surv[(size_t)(n0 + ql) * a.cap + pos] = key;
-    }
+    if (!__any(nh > 0)) return;
+    // allocate the queued hits' list slots with back-to-back atomics, then store
+    unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    if (nh > 0) p0 = atomicAdd(a.count + n0 + hq0, 1u);
+    if (nh > 1) p1 = atomicAdd(a.count + n0 + hq1, 1u);
+    if (nh > 2) p2 = atomicAdd(a.count + n0 + hq2, 1u);
+    if (nh > 3) p3 = atomicAdd(a.count + n0 + hq3, 1u);
+    if (nh > 0 && p0 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq0) * a.cap + p0] = hk0;
+    if (nh > 1 && p1 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq1) * a.cap + p1] = hk1;
+    if (nh > 2 && p2 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq2) * a.cap + p2] = hk2;
+    if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
 
 template <int METRIC, int DBG = 0, bool I8 = false>
