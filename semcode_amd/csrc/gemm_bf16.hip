@@ -269,27 +269,38 @@ static __device__ __forceinline__ void gemm256_epilogue_lna(const GemmArgs& a, i
         c2v[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's statistics DMA has landed
-    const char* sl = smem + w * 16384 + fr * 8;
-    const float inv_k = 1.0f / (float)a.K;
+    // (mu, rs) of the wave's 128 rows: lane ln finalises rows 2 ln and 2 ln + 1 ONCE (every lane doing its own 8 rows cost 8 divide
+    // + square-root sequences per lane: +29 / +52 us per QKV / FFN1 launch, gpurun_out/prof_fold1) and parks them in place of
+    // slot 0; v_rsq_f32 (1 ulp) is ample in front of a bf16 rounding.
+    char* slice = smem + w * 16384;
+    {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};  // {sum, sumsq} of row 2 ln | of row 2 ln + 1
+        for (int t = 0; t < a.stat_slots; ++t) sacc += *reinterpret_cast<const f32x4*>(slice + t * 1024 + ln * 16);
+        const float inv_k = 1.0f / (float)a.K;
+        const float mu0 = sacc[0] * inv_k, mu1 = sacc[2] * inv_k;
+        const float rs0 = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mu0, mu0, sacc[1] * inv_k), 0.f) + a.ln_eps);
+        const float rs1 = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mu1, mu1, sacc[3] * inv_k), 0.f) + a.ln_eps);
+        const f32x4 fin4 = {mu0, rs0, mu1, rs1};
+        *reinterpret_cast<f32x4*>(slice + ln * 16) = fin4;
+        if (n0 == 0 && wn == 0) *reinterpret_cast<f32x4*>(a.fin + (size_t)(m0 + wm * 128) * 2 + ln * 4) = fin4;  // for the residual epilogue of the next GEMM
+    }
+    const char* sl = slice + fr * 8;
     const size_t crs = a.cblock ? 64 : (size_t)a.ldc;
     bf16_t* cp = a.C + c_index(a, m0 + wm * 128 + prow, n0 + wn * 64) + c8;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int t = 0; t < a.stat_slots; ++t) {
-            const f32x2_t p = *reinterpret_cast<const f32x2_t*>(sl + t * 1024 + mi * 128);
-            s1 += p[0];
-            s2 += p[1];
-        }
-        const float mu = s1 * inv_k;
-        const float var = fmaxf(s2 * inv_k - mu * mu, 0.f);
-        const float rs = 1.0f / sqrtf(var + a.ln_eps);
-        if (n0 == 0 && wn == 0 && fq == 0) *reinterpret_cast<f32x2_t*>(a.fin + (size_t)(m0 + wm * 128 + mi * 16 + fr) * 2) = f32x2_t{mu, rs};
+        const f32x2_t st = *reinterpret_cast<const f32x2_t*>(sl + mi * 128);
+        const float mu = st[0], rs = st[1];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(rs, fmaf(-mu, c1v[ni][r], acc[ni][mi][r]), c2v[ni][r]);
+            // rs (acc - mu c1) + c2  as  rs acc + (c2 - rs mu c1): two packed FMAs per pair of values (the epilogue is VALU bound: every
+            // op per value costs ~0.55 us per tile)
+            const f32x2 nrm = {-rs * mu, -rs * mu}, rs2 = {rs, rs};
+            const f32x2 d01 = __builtin_elementwise_fma(nrm, f32x2{c1v[ni][0], c1v[ni][1]}, f32x2{c2v[ni][0], c2v[ni][1]});
+            const f32x2 d23 = __builtin_elementwise_fma(nrm, f32x2{c1v[ni][2], c1v[ni][3]}, f32x2{c2v[ni][2], c2v[ni][3]});
+            const f32x2 v01 = __builtin_elementwise_fma(rs2, f32x2{acc[ni][mi][0], acc[ni][mi][1]}, d01);
+            const f32x2 v23 = __builtin_elementwise_fma(rs2, f32x2{acc[ni][mi][2], acc[ni][mi][3]}, d23);
+            f32x4 v = {v01[0], v01[1], v23[0], v23[1]};
             if (EPI == EPI_LNA_GELU) {
                 const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
                 v = f32x4{g0[0], g0[1], g1[0], g1[1]};
