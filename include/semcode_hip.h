@@ -191,6 +191,9 @@ sc_status sc_diag_gemm_trace(sc_runtime* rt, int32_t epi, int32_t M, int32_t N, 
 /* The int8 form of the 256 x 256 tile (the batched scan's int8 coarse stage) on its own: out [M,N] i32 = A [M,K] i8 * W [N,K]^T,
  * exact.  M, N multiples of 256, K multiple of 128. */
 sc_status sc_diag_gemm_i8(sc_runtime* rt, const int8_t* A, const int8_t* W, int32_t M, int32_t N, int32_t K, int32_t* out);
+/* Copies one workspace buffer of the encoder's last forward to the host (kernel debugging: 0 x, 1 y, 2 qkv, 3 ctx, 4 ffn hidden,
+ * 5 / 6 partial row statistics, 7 / 8 finalised row statistics of the LayerNorm-folded pipeline). */
+sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t nbytes);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
 sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);
 

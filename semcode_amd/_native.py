@@ -76,6 +76,7 @@ SIGNATURES = {
     "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sc_diag_gemm_trace": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "sc_diag_gemm_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sc_diag_encoder_read": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_index_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "sc_index_destroy": (C.c_int32, [C.c_void_p]),

@@ -182,6 +182,15 @@ struct ResLnTailHook {
     }
 };
 
+// A scalar broadcast to both halves of a packed-f32 operand, as a real 64-bit register pair.  Left to itself hipcc encodes such a
+// broadcast with the VOP3P selects (op_sel / op_sel_hi) on whatever register holds the scalar, and one of those forms --
+// "v_pk_mul_f32 D, S0, S1 op_sel:[0,1]", the LOW result lane taking the HIGH register of src1 -- intermittently returned 0 in
+// lanes 48..63 of the low result on MI355X while other waves of the CU were still in their MFMA loop (first waves into the
+// epilogue, row blocks 0..2; operands verified correct in registers, ~2e-4 of the instances; gpurun_out/dbg_fold4..6: the same
+// multiply with an explicit pair, with the operands swapped (op_sel:[1,0]) or as two v_mul_f32 never failed, s_nop in front did
+// not help).  The 256-tile epilogues therefore carry no op_sel on a packed-f32 operand: tests/test_isa.py greps the ISA for it.
+#define SC_OPAQUE_PAIR(p) asm volatile("" : "+v"(p))
+
 // Epilogue: the MFMA layout gives each lane 4 columns of 16 different rows (32-byte row segments per store).  Each
 // wave stages one 16-row x 64-column block at a time as bf16 in its private LDS slice BEHIND the pipeline buffers and
 // stores whole 128-byte row segments, 16 B per lane.  bias, GELU and the residual (read from LDS, see above) are applied
@@ -291,11 +300,13 @@ static __device__ __forceinline__ void gemm256_epilogue_lna(const GemmArgs& a, i
     for (int mi = 0; mi < 8; ++mi) {
         const f32x2_t st = *reinterpret_cast<const f32x2_t*>(sl + mi * 128);
         const float mu = st[0], rs = st[1];
+        f32x2 nrm = {-rs * mu, -rs * mu}, rs2 = {rs, rs};
+        SC_OPAQUE_PAIR(nrm);  // broadcasts as real register pairs, see SC_OPAQUE_PAIR
+        SC_OPAQUE_PAIR(rs2);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             // rs (acc - mu c1) + c2  as  rs acc + (c2 - rs mu c1): two packed FMAs per pair of values (the epilogue is VALU bound: every
             // op per value costs ~0.55 us per tile)
-            const f32x2 nrm = {-rs * mu, -rs * mu}, rs2 = {rs, rs};
             const f32x2 d01 = __builtin_elementwise_fma(nrm, f32x2{c1v[ni][0], c1v[ni][1]}, f32x2{c2v[ni][0], c2v[ni][1]});
             const f32x2 d23 = __builtin_elementwise_fma(nrm, f32x2{c1v[ni][2], c1v[ni][3]}, f32x2{c2v[ni][2], c2v[ni][3]});
             const f32x2 v01 = __builtin_elementwise_fma(rs2, f32x2{acc[ni][mi][0], acc[ni][mi][1]}, d01);
@@ -354,16 +365,20 @@ static __device__ __forceinline__ void gemm256_epilogue_resln(const GemmArgs& a,
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         if (mi + 1 < 8) read_res(mi + 1, rr[(mi + 1) & 1]);
-        const float mu = st[mi][0], rs = st[mi][1];
+        f32x2 nmu2 = {-st[mi][0], -st[mi][0]}, rs2 = {st[mi][1], st[mi][1]};
+        SC_OPAQUE_PAIR(nmu2);  // broadcasts as real register pairs, see SC_OPAQUE_PAIR
+        SC_OPAQUE_PAIR(rs2);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const u32x2 r2 = rr[mi & 1][ni];
-            const f32x4 rv = f32x4{__builtin_bit_cast(float, r2[0] << 16), __builtin_bit_cast(float, r2[0] & 0xFFFF0000u),
-                                   __builtin_bit_cast(float, r2[1] << 16), __builtin_bit_cast(float, r2[1] & 0xFFFF0000u)};
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(rv[r] - mu, rs * gam4[ni][r], acc[ni][mi][r] + bias4[ni][r]);
+            const f32x2 rv01 = {__builtin_bit_cast(float, r2[0] << 16), __builtin_bit_cast(float, r2[0] & 0xFFFF0000u)};
+            const f32x2 rv23 = {__builtin_bit_cast(float, r2[1] << 16), __builtin_bit_cast(float, r2[1] & 0xFFFF0000u)};
+            const f32x2 v01 = __builtin_elementwise_fma(rv01 + nmu2, rs2 * f32x2{gam4[ni][0], gam4[ni][1]},
+                                                        f32x2{acc[ni][mi][0], acc[ni][mi][1]} + f32x2{bias4[ni][0], bias4[ni][1]});
+            const f32x2 v23 = __builtin_elementwise_fma(rv23 + nmu2, rs2 * f32x2{gam4[ni][2], gam4[ni][3]},
+                                                        f32x2{acc[ni][mi][2], acc[ni][mi][3]} + f32x2{bias4[ni][2], bias4[ni][3]});
+            const f32x4 v = {v01[0], v01[1], v23[0], v23[1]};
             const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<u32x2*>(stg + fr * T_EPI_ROW + (ni * 16 + 4 * fq) * 2) = u32x2{p0, p1};
             // statistics of what the consumer will read: the rounded values

@@ -597,6 +597,18 @@ extern "C" sc_status sc_encoder_set_path(sc_encoder* e, int32_t path) {
     return SC_OK;
 }
 
+// Diagnostic: copy one workspace buffer of the last forward to the host (0 x, 1 y, 2 qkv, 3 ctx, 4 hm, 5 stat_a, 6 stat_b, 7 fin_a, 8 fin_b).
+extern "C" sc_status sc_diag_encoder_read(sc_encoder* e, int32_t which, void* out, size_t nbytes) {
+    if (!e || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_encoder_read: NULL argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    const void* src[9] = {e->x, e->y, e->qkv, e->ctx, e->hm, e->stat_a, e->stat_b, e->fin_a, e->fin_b};
+    if (which < 0 || which > 8 || !src[which]) return sc_fail(SC_ERR_INVALID, "sc_diag_encoder_read: no such buffer");
+    SC_HIP(hipSetDevice(e->rt->device));
+    SC_HIP(hipStreamSynchronize(e->rt->stream));
+    SC_HIP(hipMemcpy(out, src[which], nbytes, hipMemcpyDeviceToHost));
+    return SC_OK;
+}
+
 extern "C" sc_status sc_encoder_info(sc_encoder* e, sc_encoder_cfg* cfg_out) {
     if (!e || !cfg_out) return sc_fail(SC_ERR_INVALID, "sc_encoder_info: NULL argument");
     *cfg_out = e->cfg;

@@ -210,8 +210,11 @@ def test_encoder_full_size_properties(rt):
     # the 1-token chunk is not averaged over tokens, so it carries the full per-token bf16 noise of 12 layers: looser absolute bar
     one, ref1 = a[5], want[1]
     assert one @ ref1 / (np.linalg.norm(one) * np.linalg.norm(ref1)) >= 0.999 and np.abs(one - ref1).max() <= 0.1
-    small = enc.embed_ids(ids[sample[:3]], lens[sample[:3]])  # 768 tokens: split-K GEMMs
-    assert np.abs(small - a[sample[:3]]).max() <= 2e-2  # same arithmetic up to the summation order of the K slices
+    # 768 tokens: split-K GEMMs and stand-alone LayerNorm kernels, against the batch pipeline's LayerNorm-folded GEMMs (the same
+    # function, rounded to bf16 at different points); the 1-token chunk again gets the per-token bar
+    small = enc.embed_ids(ids[sample[:3]], lens[sample[:3]])
+    assert np.abs(small[[0, 2]] - a[[0, 77]]).max() <= 2e-2
+    assert small[1] @ a[5] / (np.linalg.norm(small[1]) * np.linalg.norm(a[5])) >= 0.999 and np.abs(small[1] - a[5]).max() <= 0.1
     enc.close()
 
 
