@@ -155,7 +155,7 @@ def bench_embed(ctx, args) -> dict:
         "chunks_per_s": chunks_s,
         "ms_per_step": 1e3 * dt / args.steps,
         "workload": f"encoder forward, {B} chunks x {S} tokens per GPU per step, BERT-base shape (12x768, 12 heads, FFN 3072), bf16 MFMA / f32 accumulate, random-init weights",
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_kernel (LayerNorm-folded epilogues: the launches also do the two LayerNorms per layer)", "achieved": gemm_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_BF16_PEAK_TFLOPS if gemm_tflops else None,
                      "traffic": (pmc_traffic() or {}).get("gemm256_bf16_kernel", {}).get("traffic_bytes_per_launch") if (B, S) == (256, 256) else None,
                      "traffic_note": f"bytes per launch (avg of the 4 GEMM shapes), {(pmc_traffic() or {}).get('_file')}; algorithmic A+W+C(+R) = 4.56e8",

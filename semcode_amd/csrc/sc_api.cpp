@@ -739,7 +739,12 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
 
 static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
     const int env = coarse_pin(ix);
-    const bool i8 = env == 8 || (env == 0 && !ix->i8_off);
+    // The int8 stage halves the coarse GEMM but re-ranks 512 candidates per query instead of 128 (512 * ld * 4 B of scattered rows
+    // each): it pays from about a million rows up (10M x 768: coarse 12.9 -> 7.0 ms against +0.3 ms of re-rank).  Small corpora --
+    // above all the IVF quantizer, whose nearest-centroid searches of a build went 6.4 -> 16.4 s through it at 4096 x 3072
+    // (profiles/r2i_kernel_stats.csv: scan_rerank_kernel 7.4 s) -- start at the bf16 stage.
+    // (search mode 2, "batched whenever supported", is the tests' switch: it keeps the int8 stage eligible at any size.)
+    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && (ix->n >= ((int64_t)1 << 20) || ix->search_mode == 2));
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
     ix->last_uncertified = 0;

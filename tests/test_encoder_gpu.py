@@ -218,6 +218,37 @@ def test_encoder_full_size_properties(rt):
     enc.close()
 
 
+def test_batch_pipeline_is_reproducible_run_to_run(rt):
+    """Six forwards of the same 256 x 256-token batch through the LayerNorm-folded pipeline, 2 layers of BERT-base shape with
+    non-trivial biases and LayerNorm parameters: every buffer of the last layer (out-projection output, its row statistics, FFN
+    output) and the pooled vectors repeat bit for bit.  This is the regression test of the packed-f32 op_sel hazard (DESIGN.md
+    section 9): it showed as ~500 differing elements of the out-projection output per forward."""
+    import ctypes as C
+
+    cfg = dict(bo.BERT_BASE, layers=2, vocab=4000)
+    enc = _native.Encoder(rt, cfg, weights=bo.make_blob(cfg, 11, "test"))
+    enc.set_path("batch")
+    rng = np.random.default_rng(4)
+    ids = rng.integers(1, 4000, size=(256, 256)).astype(np.int32)
+    lens = np.full(256, 256, np.int32)
+    M = 256 * 256
+
+    def snapshot():
+        out = [enc.embed_ids(ids, lens).copy()]
+        for which, nbytes in ((0, M * 768 * 2), (1, M * 768 * 2), (5, 3 * M * 8), (7, M * 8)):
+            buf = np.empty(nbytes, np.uint8)
+            _native._check(_native.lib().sc_diag_encoder_read(enc.handle, which, buf.ctypes.data_as(C.c_void_p), nbytes))
+            out.append(buf)
+        return out
+
+    first = snapshot()
+    for _ in range(5):
+        again = snapshot()
+        for k, (x, y) in enumerate(zip(first, again)):
+            assert np.array_equal(x, y), (k, int((x != y).sum()))
+    enc.close()
+
+
 def test_encoder_bad_arguments(rt):
     with pytest.raises(_native.ScError):
         _native.Encoder(rt, dict(bo.BERT_BASE, hidden=96, heads=2))  # head dim != 64
