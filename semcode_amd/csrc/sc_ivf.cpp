@@ -41,10 +41,14 @@ static sc_status assign_rows(sc_index* ix, const float* q_dev_tight, int64_t n, 
     for (int64_t r0 = 0; r0 < n; r0 += ASSIGN_CHUNK) {
         const int m = (int)std::min<int64_t>(ASSIGN_CHUNK, n - r0);
         std::lock_guard<std::mutex> g(qz->mu);
-        const int saved_mode = qz->search_mode;
+        const int saved_mode = qz->search_mode, saved_coarse = qz->coarse_mode;
         qz->search_mode = 2;  // thousands of queries against few centroids: the MFMA path, certified exact
+        // ... starting at the bf16 stage: against a few thousand centroids the int8 stage saves nothing in the coarse pass and
+        // re-ranks 512 candidates per row instead of 128 (a 10M x 3072 build: 6.4 s vs 16.4 s, profiles/r2i_kernel_stats.csv)
+        if (qz->coarse_mode == 0) qz->coarse_mode = 16;
         st = sc_search_flat_locked(qz, q_dev_tight + r0 * ix->dim, m, 1, dd, dr);
         qz->search_mode = saved_mode;
+        qz->coarse_mode = saved_coarse;
         if (st) return st;
         SC_HIP(hipMemcpyAsync(host.data(), dr, (size_t)m * 8, hipMemcpyDeviceToHost, s));
         SC_HIP(hipStreamSynchronize(s));
@@ -489,29 +493,43 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     }
     // long lists are cut into parts of at most `target` rows (each part its own group) so that no single workgroup streams a
     // 20k-row list while the others idle; a query then merges up to nprobe * maxparts partial lists
-    int64_t work_rows = 0, longest = 0;
+    // Wide groups (scan_listgemm_kernel): a list probed by more than qt queries is cut into chunks of up to 64 queries, each
+    // streamed ONCE with 4 x the arithmetic per row byte (the matrix pipe, not the row stream, bounds it); a remainder of at most
+    // qt queries joins the narrow classes.  SC_IVF_WIDE=0 switches the class off (A/B, tests of the narrow classes).
+    const int qw = sc_scan_listgemm_width();
+    bool wide_ok = sc_scan_listgemm_supported(ix->ld, k) && qt == 16;
+    if (const char* e = getenv("SC_IVF_WIDE"))
+        if (e[0] == '0') wide_ok = false;
+    int64_t work_rows = 0, work_rows_w = 0, longest = 0;
     for (int l = 0; l < nlist; ++l) {
         const int m = start[(size_t)l + 1] - start[(size_t)l];
         const int64_t len = ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
         if (m == 0 || len <= 0) continue;
-        work_rows += len * ((m + qt - 1) / qt);
+        int mw = 0, c = 0;  // wide chunks of this list
+        while (wide_ok && m - c > qt) { ++mw; c += std::min(qw, m - c); }
+        work_rows_w += len * mw;
+        work_rows += len * ((m - c + qt - 1) / qt);
         longest = std::max(longest, len);
     }
+    // parts: ~8 narrow groups per CU (each streams at the LDS-DMA rate), ~6 wide ones (each 2.5 x longer per row)
     int64_t target = std::min<int64_t>(8192, std::max<int64_t>(512, work_rows / ((int64_t)rt->cus * 8)));
     target = (target + 15) & ~(int64_t)15;
-    int maxparts = (int)((longest + target - 1) / std::max<int64_t>(target, 16));
-    if (maxparts < 1) maxparts = 1;
+    int64_t target_w = std::min<int64_t>(8192, std::max<int64_t>(512, work_rows_w / ((int64_t)rt->cus * 6)));
+    target_w = (target_w + 63) & ~(int64_t)63;
+    auto parts_of = [&](int64_t len) { return (int)std::max<int64_t>((len + target - 1) / target, wide_ok ? (len + target_w - 1) / target_w : 0); };
+    int maxparts = std::max(1, parts_of(longest));
     while (maxparts > 1 && !sc_topk_gather_merge_supported(nprobe * maxparts, k)) {  // merge capacity: fewer, longer parts
         target *= 2;
-        maxparts = (int)((longest + target - 1) / target);
+        target_w *= 2;
+        maxparts = std::max(1, parts_of(longest));
     }
     const int L = nprobe * maxparts;
-    std::vector<int32_t> src((size_t)Q * L, -1), qmap;
+    std::vector<int32_t> src((size_t)Q * L, -1), qmap, qmap_w;
     std::vector<int> sb;
-    std::vector<int64_t> sr;
+    std::vector<int64_t> sr, sr_w;
     // With the streamed-query scan (long rows, qt = 16) a group of few queries is still better off on the resident variant,
-    // which streams ~30 % faster: groups are numbered in two classes -- first those with more queries than fit resident
-    // (qt_res), then the small ones -- and each class gets its own launch over the one (group, slot) numbering of stride qt.
+    // which streams ~30 % faster: groups are numbered in classes -- the wide ones first (below), then those with more queries
+    // than fit resident (qt_res), then the small ones -- and each class gets its own launch.
     ScanPlan plan_res = plan;
     if (plan.qstream && !sc_scan_exact_plan(ix->ld, 16, k, rt->cus, &plan_res, 16, 1)) plan_res = plan;
     int qt_res = plan_res.qstream ? qt : std::min(qt, plan_res.qt);
@@ -519,50 +537,69 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         if (plan.qstream && e[0] != '0') qt_res = 0;  // forced: every group on the streamed variant (tests, A/B)
     // Within a class the longest parts go first: one workgroup streams one group, and a 100 MB part that starts in the last
     // round would leave the other CUs idle for its whole length (stable sort: the numbering stays deterministic).
-    struct GroupDesc { int l, c, part; int64_t p0, p1; };
+    struct GroupDesc { int l, c, nqg, part; int64_t p0, p1; };
     std::vector<GroupDesc> descs;
-    int G = 0, G_big = 0;
-    for (int cls = 0; cls < 2; ++cls) {
+    int G = 0, G_big = 0, Gw = 0;          // narrow groups (G_big of them on the streamed variant), wide groups
+    int64_t lists_w = 0;                    // k-lists of the wide class: they come first in `partial`
+    for (int cls = -1; cls < 2; ++cls) {    // -1 wide, 0 narrow / streamed queries, 1 narrow / resident queries
+        if (cls == 0) lists_w = (int64_t)Gw * qw;
         if (cls == 1) G_big = G;
+        if (cls == -1 && !wide_ok) continue;
         descs.clear();
         for (int l = 0; l < nlist; ++l) {
             const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
             const int m = start[(size_t)l + 1] - start[(size_t)l];
             if (m == 0 || end <= first) continue;  // nobody probes it / empty list
-            const int parts = (int)((end - first + target - 1) / target);
-            for (int c = 0; c < m; c += qt) {
-                if ((std::min(qt, m - c) > qt_res) != (cls == 0)) continue;
-                for (int part = 0; part < parts; ++part) {
-                    const int64_t p0 = first + (int64_t)part * target;
-                    descs.push_back({l, c, part, p0, std::min(end, p0 + target)});
+            // the chunks of this list's queries: wide ones of up to qw while more than qt remain, then narrow ones of up to qt
+            int c = 0;
+            while (c < m) {
+                const bool wide = wide_ok && m - c > qt;
+                const int nqg = std::min(wide ? qw : qt, m - c);
+                const int want = wide ? -1 : (nqg > qt_res ? 0 : 1);
+                if (want == cls) {
+                    const int64_t tg = wide ? target_w : target;
+                    const int parts = (int)((end - first + tg - 1) / tg);
+                    for (int part = 0; part < parts; ++part) {
+                        const int64_t p0 = first + (int64_t)part * tg;
+                        descs.push_back({l, c, nqg, part, p0, std::min(end, p0 + tg)});
+                    }
                 }
+                c += nqg;
             }
         }
         std::stable_sort(descs.begin(), descs.end(), [](const GroupDesc& x, const GroupDesc& y) { return x.p1 - x.p0 > y.p1 - y.p0; });
         for (const GroupDesc& d : descs) {
-            const int m = start[(size_t)d.l + 1] - start[(size_t)d.l];
-            for (int sl = 0; sl < qt; ++sl) {
-                if (d.c + sl < m) {
+            const int stride = cls < 0 ? qw : qt;
+            const int64_t base = cls < 0 ? (int64_t)Gw * qw : lists_w + (int64_t)G * qt;
+            std::vector<int32_t>& qm = cls < 0 ? qmap_w : qmap;
+            for (int sl = 0; sl < stride; ++sl) {
+                if (sl < d.nqg) {
                     const int32_t pair = pair_of[(size_t)start[(size_t)d.l] + d.c + sl];
                     const int q = pair / nprobe, j = pair - q * nprobe;
-                    qmap.push_back(q);
-                    src[(size_t)q * L + (size_t)j * maxparts + d.part] = G * qt + sl;
+                    qm.push_back(q);
+                    src[(size_t)q * L + (size_t)j * maxparts + d.part] = (int32_t)(base + sl);
                 } else {
-                    qmap.push_back(-1);
+                    qm.push_back(-1);
                 }
             }
-            sb.push_back(0);
-            sb.push_back((int)((d.p1 - d.p0 + 15) >> 4));
-            sr.push_back(d.p0);
-            sr.push_back(d.p1);
-            ++G;
+            if (cls < 0) {
+                sr_w.push_back(d.p0);
+                sr_w.push_back(d.p1);
+                ++Gw;
+            } else {
+                sb.push_back(0);
+                sb.push_back((int)((d.p1 - d.p0 + 15) >> 4));
+                sr.push_back(d.p0);
+                sr.push_back(d.p1);
+                ++G;
+            }
         }
     }
     const double t_plan = since();
     // 3. plan tables -> device (they replace the probe results in the scratch buffer), queries padded + normed
     off = 0;
     const size_t o_src = carve(src.size() * 4), o_qmap = carve((size_t)G * qt * 4 + 16), o_sb = carve((size_t)G * 2 * 4 + 16),
-                 o_sr = carve((size_t)G * 2 * 8 + 16);
+                 o_sr = carve((size_t)G * 2 * 8 + 16), o_qmap_w = carve((size_t)Gw * qw * 4 + 16), o_sr_w = carve((size_t)Gw * 2 * 8 + 16);
     st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, off);
     if (st) return st;
     b = (char*)ix->ivf_scratch;
@@ -572,16 +609,23 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         SC_HIP(hipMemcpyAsync(b + o_sb, sb.data(), (size_t)G * 2 * 4, hipMemcpyHostToDevice, s));
         SC_HIP(hipMemcpyAsync(b + o_sr, sr.data(), (size_t)G * 2 * 8, hipMemcpyHostToDevice, s));
     }
+    if (Gw > 0) {
+        SC_HIP(hipMemcpyAsync(b + o_qmap_w, qmap_w.data(), (size_t)Gw * qw * 4, hipMemcpyHostToDevice, s));
+        SC_HIP(hipMemcpyAsync(b + o_sr_w, sr_w.data(), (size_t)Gw * 2 * 8, hipMemcpyHostToDevice, s));
+    }
     st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
     if (st) return st;
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
-    st = sc_grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>((size_t)G * qt * k * 8, 16));
+    st = sc_grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>(((size_t)lists_w + (size_t)G * qt) * k * 8, 16));
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ix->ld, ix->qnorm, s);
-    // 4. one workgroup per group (grid.y is limited to 65535 groups per launch)
+    // 4. one workgroup per group (grid.y is limited to 65535 groups per launch); the wide class goes first: its workgroups are
+    // the long ones
     hipEvent_t e0, e1;
     sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+    sc_launch_scan_listgemm((int)ix->metric, ix->X, ix->xnorm, ix->ld, ix->qpad, ix->qnorm, k, Gw, ix->partial, ix->perm,
+                            (const int64_t*)(b + o_sr_w), (const int32_t*)(b + o_qmap_w), s);
     for (int cls = 0; cls < 2; ++cls)
       for (int g0 = cls ? G_big : 0, hi = cls ? G : G_big; g0 < hi; g0 += 65535) {
         const int gn = std::min(65535, hi - g0);
@@ -591,7 +635,7 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         p.lists = 1;
         p.gstride = qt;
         sc_launch_scan_exact((int)ix->metric, ix->X, ix->xnorm, ix->n, ix->ld, ix->qpad, ix->qnorm, gn * qt, k, p,
-                             ix->partial + (size_t)g0 * qt * k, ix->perm, (const int*)(b + o_sb) + (size_t)g0 * 2,
+                             ix->partial + ((size_t)lists_w + (size_t)g0 * qt) * k, ix->perm, (const int*)(b + o_sb) + (size_t)g0 * 2,
                              (const int64_t*)(b + o_sr) + (size_t)g0 * 2, 1, s, (const int32_t*)(b + o_qmap) + (size_t)g0 * qt);
     }
     sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
@@ -605,16 +649,21 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
             streamed += (double)(sr[g + 1] - sr[g]);
             if ((int)(g / 2) < G_big) streamed_big += (double)(sr[g + 1] - sr[g]);
         }
+        double streamed_wide = 0.0;
+        for (size_t g = 0; g < sr_w.size(); g += 2) streamed_wide += (double)(sr_w[g + 1] - sr_w[g]);
+        streamed += streamed_wide;
+        fprintf(stderr, "[ivf list-major] wide groups (<= %d queries each): %d = %.1f GB\n", qw, Gw, streamed_wide * (double)ix->ld * 4.0 / 1e9);
         streamed *= (double)ix->ld * 4.0;
         streamed_big *= (double)ix->ld * 4.0;
         const double t_scan = since() - t_plan;
-        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d (%d = %.1f GB on streamed queries) parts<=%d target=%lld rows | D2H of probes %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms = %.1f GB at %.2f TB/s\n",
-                Q, nprobe, qt, G, plan.qstream ? G_big : 0, plan.qstream ? streamed_big / 1e9 : 0.0, maxparts, (long long)target, t_probe, t_plan - t_probe, t_scan, streamed / 1e9, streamed / 1e9 / t_scan);
+        fprintf(stderr, "[ivf list-major] Q=%d nprobe=%d qt=%d groups=%d (%d = %.1f GB on streamed queries) parts<=%d target=%lld / %lld rows | D2H of probes %.3f ms, host plan %.3f ms, H2D + scan + merge %.3f ms = %.1f GB at %.2f TB/s\n",
+                Q, nprobe, qt, G, plan.qstream ? G_big : 0, plan.qstream ? streamed_big / 1e9 : 0.0, maxparts, (long long)target, (long long)target_w, t_probe, t_plan - t_probe, t_scan, streamed / 1e9, streamed / 1e9 / t_scan);
     }
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;
-    ix->last_groups = G;
+    ix->last_groups = G + Gw;
     for (size_t g = 0; g < sr.size(); g += 2) ix->last_streamed_rows += sr[g + 1] - sr[g];
+    for (size_t g = 0; g < sr_w.size(); g += 2) ix->last_streamed_rows += sr_w[g + 1] - sr_w[g];
     for (int l = 0; l < nlist; ++l)
         if (start[(size_t)l + 1] > start[(size_t)l]) ix->last_unique_rows += ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
     return SC_OK;

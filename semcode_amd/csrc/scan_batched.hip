@@ -21,6 +21,10 @@
 // survivor list overflowed) are flagged and re-run through the exact scan by the host code.
 //
 // Roofline: MFMA bf16; algorithmic FLOPs = 2 * rows * ld * Qpad per phase launch.
+#include <map>
+#include <vector>
+#include <algorithm>
+#include <cstdio>
 #include <algorithm>
 #include <cstdlib>
 
@@ -199,6 +203,7 @@ struct CoarseArgs {
     int ntiles;
     const float* xscale;   // int8 stage: s_r per corpus row (rows padded to 256 hold anything finite)
     const float* qscale;   // int8 stage: s_q per query [Qpad]
+    unsigned long long* trace;  // DBG = 2 (SC_COARSE_TRACE): [ntiles][4] = HW_ID | XCC_ID << 32, t_entry, t_mainloop_done, t_end (100 MHz)
 };
 
 template <int METRIC>
@@ -296,7 +301,13 @@ static __device__ __forceinline__ void coarse256_coords(const CoarseArgs& a, int
 // A variant without that branch -- every lane that passes the bound runs the precise test under its own exec mask and parks
 // its key in a per-wave LDS list flushed once per tile -- was measured on the same box and lost (int8 stage 11.25 -> 12.28 ms,
 // bf16 15.05 -> 16.2 ms per step, gpurun_out/r2f_scan_*.log): the divergent bodies cost more than the uniform branch saves.
-template <int METRIC, bool I8 = false>
+// So did a two-phase form (branch-free bound tests into a 32-bit group mask, DPP OR over the wave, then a loop over the set bits
+// with the precise test present once and the accumulators fetched by a switch): the per-workgroup stamps (SC_COARSE_TRACE,
+// profiles/r2j_coarse_trace.log) put this version at 3.4 / 4.4 us of epilogue per tile with 10 / 35 of 256 groups entering the
+// precise test (0.46 us of that is wave skew, ~1.9 us the 32 bound tests: a wave64 VALU instruction issues over 4 cycles and two
+// waves share a SIMD), the two-phase form at 3.4-3.7 / 5.5-6.2 us -- its loop body costs more per entered group than 32 unrolled
+// copies do.  Removing the returning atomics changed nothing (4.3 vs 4.4 us).
+template <int METRIC, bool I8 = false, bool TRACE = false, bool NOATOM = false, bool NOPRECISE = false>
 static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
                                                           int lane) {
     const int wm = w >> 2, wn = w & 3;
@@ -350,7 +361,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
             } else {
                 g = (acc[ni][mi][0] >= Tlb) | (acc[ni][mi][1] >= Tlb) | (acc[ni][mi][2] >= Tlb) | (acc[ni][mi][3] >= Tlb);
             }
-            if (!__any(g)) continue;
+            if (!__any(g) || NOPRECISE) continue;  // NOPRECISE: diagnostic (results invalid), what the bound tests alone cost
+            if (TRACE && lane == 0) atomicAdd(&a.trace[(size_t)blockIdx.x * 8 + 4], 1ull);
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -369,12 +381,14 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (row < a.row1 && t[r] <= tf[ni][r]) {
+                        if (TRACE) atomicAdd(&a.trace[(size_t)blockIdx.x * 8 + 5], 1ull);
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
                         const float accv = acc[ni][mi][r];
                         const float dotv = I8 ? (float)__float_as_int(accv) * (sx * sq[ni][r]) : accv;
                         const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= q_thr[ql]) {  // q_thr = -inf for padded queries
+                            if (TRACE) atomicAdd(&a.trace[(size_t)blockIdx.x * 8 + 6], 1ull);
                             const uint64_t key = sc_make_key<METRIC>(sc, (uint32_t)row);
                             if (nh == 0) { hq0 = ql; hk0 = key; }
                             else if (nh == 1) { hq1 = ql; hk1 = key; }
@@ -394,10 +408,14 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     if (!__any(nh > 0)) return;
     // allocate the queued hits' list slots with back-to-back atomics, then store
     unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    if (nh > 0) p0 = atomicAdd(a.count + n0 + hq0, 1u);
-    if (nh > 1) p1 = atomicAdd(a.count + n0 + hq1, 1u);
-    if (nh > 2) p2 = atomicAdd(a.count + n0 + hq2, 1u);
-    if (nh > 3) p3 = atomicAdd(a.count + n0 + hq3, 1u);
+    if (NOATOM) {  // diagnostic (results invalid): what the returning atomics cost
+        p0 = lane; p1 = 64 + lane; p2 = 128 + lane; p3 = 192 + lane;
+    } else {
+        if (nh > 0) p0 = atomicAdd(a.count + n0 + hq0, 1u);
+        if (nh > 1) p1 = atomicAdd(a.count + n0 + hq1, 1u);
+        if (nh > 2) p2 = atomicAdd(a.count + n0 + hq2, 1u);
+        if (nh > 3) p3 = atomicAdd(a.count + n0 + hq3, 1u);
+    }
     if (nh > 0 && p0 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq0) * a.cap + p0] = hk0;
     if (nh > 1 && p1 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq1) * a.cap + p1] = hk1;
     if (nh > 2 && p2 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq2) * a.cap + p2] = hk2;
@@ -411,7 +429,13 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int64_t m0;
     int n0;
+    if ((DBG & 2) && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 8 + 0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        a.trace[(size_t)blockIdx.x * 8 + 1] = (unsigned long long)wall_clock64();
+    }
     coarse256_coords(a, xcd_remap(blockIdx.x, a.ntiles), m0, n0);
+    // (requesting the first two K-tiles before this staging -- so that the two memory round trips overlap -- measured no change:
+    // entry -> main loop done stayed at 11.2 us per int8 tile)
     coarse256_stage<I8>(a, m0, n0, smem, tid);
     f32x4 acc[4][8];
 #pragma unroll
@@ -422,16 +446,25 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     gemm_tile256_mainloop<0, NoTailHook, I8>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
     asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG) {  // diagnostic: main loop only
+    if ((DBG & 2) && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)wall_clock64();
+    if (DBG & 1) {  // diagnostic: main loop only
         float sink = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][3];
         if (sink == 12345.678f) a.count[0] = 1;
+        if (DBG & 2) {
+            __syncthreads();
+            if (tid == 0) a.trace[(size_t)blockIdx.x * 8 + 3] = (unsigned long long)wall_clock64();
+        }
         return;
     }
-    coarse256_epilogue<METRIC, I8>(a, acc, m0, n0, smem, w, lane);
+    coarse256_epilogue<METRIC, I8, (DBG & 2) != 0, (DBG & 4) != 0, (DBG & 8) != 0>(a, acc, m0, n0, smem, w, lane);
+    if (DBG & 2) {
+        __syncthreads();
+        if (tid == 0) a.trace[(size_t)blockIdx.x * 8 + 3] = (unsigned long long)wall_clock64();
+    }
 }
 
 // A persistent variant (one workgroup per CU walking tiles b, b + grid, ..., the tail hook of tile t requesting K-tiles 0 and 1 of
@@ -797,6 +830,59 @@ static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
 
 // i8: Xb / Qb are the int8 shadows with rows of ld8 bytes (`ld` is then ld8), xscale / qscale their per-row scales; the batch must be
 // padded to 256 queries (the int8 stage only exists on the 256 x 256 tile)
+// SC_COARSE_TRACE: one traced launch, summarised on stderr (mean us per workgroup: entry -> main loop done -> end, and the idle gap
+// between consecutive workgroups of one CU)
+static void coarse256_trace(CoarseArgs a, bool i8, hipStream_t s) {
+    unsigned long long* dev = nullptr;
+    const size_t words = (size_t)a.ntiles * 8;
+    if (hipMalloc(&dev, words * 8) != hipSuccess) return;
+    (void)hipMemsetAsync(dev, 0, words * 8, s);
+    a.trace = dev;
+    static const int mode = atoi(getenv("SC_COARSE_TRACE"));  // 1 trace, 2 trace without the returning atomics (results invalid)
+    if (i8 && mode == 3) {  // main loop only
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 3, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    } else if (i8 && mode == 4) {  // bound tests only
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 10, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    } else if (i8 && mode == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 6, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    } else if (i8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 2, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 2, false>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    }
+    std::vector<unsigned long long> h(words);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), dev, words * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
+    double ml = 0, ep = 0, taken = 0, fastpass = 0, hits = 0;
+    unsigned long long t_first = ~0ull, t_last = 0;
+    for (int t = 0; t < a.ntiles; ++t) {
+        const unsigned long long* r = &h[(size_t)t * 8];
+        taken += (double)r[4]; fastpass += (double)r[5]; hits += (double)r[6];
+        ml += (double)(r[2] - r[1]);
+        ep += (double)(r[3] - r[2]);
+        // HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13; XCC_ID low bits of the high word
+        per_cu[(r[0] >> 32) << 16 | ((r[0] >> 8) & 0xFF)].push_back({r[1], r[3]});
+        t_first = r[1] < t_first ? r[1] : t_first;
+        t_last = r[3] > t_last ? r[3] : t_last;
+    }
+    double gap = 0;
+    size_t gaps = 0;
+    for (auto& kv : per_cu) {
+        auto& v = kv.second;
+        std::sort(v.begin(), v.end());
+        for (size_t i = 1; i < v.size(); ++i) { gap += (double)((long long)v[i].first - (long long)v[i - 1].second); ++gaps; }
+    }
+    fprintf(stderr, "[coarse trace] %s tiles %d on %zu CUs, launch %.1f us: per tile entry->mainloop done %.2f us, epilogue %.2f us, gap to the next workgroup of the CU %.2f us; per tile: %.1f of 256 wave-groups entered the precise test, %.1f scores passed the fast test, %.1f survivors\n",
+            i8 ? "int8" : "bf16", a.ntiles, per_cu.size(), (double)(t_last - t_first) / 100.0, ml / a.ntiles / 100.0, ep / a.ntiles / 100.0, gaps ? gap / gaps / 100.0 : 0.0, taken / a.ntiles, fastpass / a.ntiles, hits / a.ntiles);
+}
+
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
                            int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale) {
@@ -806,6 +892,12 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
     if ((Qpad % T_BN) == 0 && (row0 % T_BM) == 0) {  // large batches: 256 x 256 tiles (corpus rows are padded to 256)
         a.qtiles = Qpad / T_BN;
         a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);
+        a.trace = nullptr;
+        static const bool trace = getenv("SC_COARSE_TRACE") != nullptr;  // diagnostic: per-workgroup time stamps of the large L2 launches -> stderr
+        if (trace && metric == SC_METRIC_L2 && a.ntiles >= 20000) {
+            coarse256_trace(a, i8, s);
+            return;
+        }
         static const bool dbg = getenv("SC_COARSE_DBG") != nullptr;  // diagnostic: time the main loop alone (results invalid)
         if (dbg) {
             if (i8) {

@@ -376,6 +376,220 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ wide groups: one list part x up to 64 queries per workgroup
+// List-major IVF probing streams a list once per GROUP of queries that probe it.  With 16 queries per group the scan above is
+// bound by its LDS-DMA row stream (4.8-5.1 TB/s at 3 072 dimensions) while the matrix pipe idles (16 MFMAs = 512 cycles per 4 KiB
+// row stage, 28 % busy), and a popular list is streamed again and again: config 5 reads 271 GB for 37.8 GB of distinct lists
+// (profiles/r2i_bench.json.log).  This kernel is the same arithmetic organised as a GEMM: a workgroup takes 64 rows x 64 queries
+// per k-chunk of 64 floats -- rows AND queries staged through a three-deep LDS ring by LDS-DMA (32 KiB per stage, the XOR swizzle
+// of the scan above), one raw barrier per k-chunk -- and wave w multiplies all 64 rows by ITS 16 queries (4 accumulators, 64
+// MFMAs = 2 048 cycles per stage): four times the arithmetic per streamed row byte, so the matrix pipe becomes the bound and a
+// list wanted by 64 queries is streamed once.  Per (row, query) the MFMA chain is the canonical one (k-chunks in order, t then c
+// inside), so scores are bit-identical to scan_exact_kernel.  Candidate lists are wave-private (a wave owns its 16 query slots
+// for every row of the group): no cross-wave merge, the wave writes its slots' sorted k-lists itself.
+#define LG_ROWS 64
+#define LG_QW 64
+#define LG_NST 3
+#define LG_STAGE_BYTES 32768  // [4 row blocks of 16 x 256 B | 4 query blocks of 16 x 256 B]
+#define LG_CAP 64             // candidates per query slot: k <= LG_CAP - 16 (a row block appends at most 16 per slot)
+#define LG_NORM_SLOTS 4
+
+struct ListGemmArgs {
+    const float* X;
+    const float* xnorm;
+    int ld;
+    const float* Qp;        // padded queries [Q][ld]
+    const float* qnorm;     // [Q]
+    int k;
+    uint64_t* partial;      // [groups][LG_QW][k] sorted keys
+    const uint32_t* perm;   // stored position -> reported row id, or NULL
+    const int64_t* seg_rows;  // [groups][2] = {first, end} stored positions of the group's list part
+    const int32_t* qmap;      // [groups][LG_QW] query rows, valid slots a prefix, -1 beyond
+};
+#define LG_LDS_RING 0
+#define LG_LDS_NORMS (LG_NST * LG_STAGE_BYTES)
+#define LG_LDS_THR (LG_LDS_NORMS + LG_NORM_SLOTS * 4 * 256)
+#define LG_LDS_CNT (LG_LDS_THR + LG_QW * 8)
+#define LG_LDS_CAND (LG_LDS_CNT + LG_QW * 4)
+#define LG_LDS_TMP (LG_LDS_CAND + LG_QW * LG_CAP * 8)
+#define LG_LDS_TOTAL (LG_LDS_TMP + SCAN_WAVES * LG_CAP * 8)
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_listgemm_kernel(ListGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int grp = blockIdx.x;
+    const int ld = a.ld, spt = ld >> 6;
+    const int64_t first = a.seg_rows[2 * (size_t)grp], end = a.seg_rows[2 * (size_t)grp + 1];
+    const int ntile = (int)((end - first + LG_ROWS - 1) / LG_ROWS);
+    const int total = ntile * spt;
+    const int32_t* qm = a.qmap + (size_t)grp * LG_QW;
+    const int nq = __popcll(__ballot(qm[lane] >= 0));  // valid slots are a prefix
+    // wave-private selection state of slots 16 w .. 16 w + 15
+    lds_u64p thr_w = (lds_u64p)(smem + LG_LDS_THR) + w * 16;
+    lds_u32p cnt_w = (lds_u32p)(smem + LG_LDS_CNT) + w * 16;
+    lds_u64p cand_w = (lds_u64p)(smem + LG_LDS_CAND) + (size_t)w * 16 * LG_CAP;
+    lds_u64p tmp_w = (lds_u64p)(smem + LG_LDS_TMP) + w * LG_CAP;
+    if (lane < 16) {
+        thr_w[lane] = SC_KEY_MAX;
+        cnt_w[lane] = 0u;
+    }
+    const int myslot = 16 * w + r16;
+    const float qn_mine = myslot < nq ? a.qnorm[qm[myslot]] : 1.0f;
+
+    // ---- LDS-DMA geometry: piece j of this wave = 4 rows (or query slots) 4 j + prow of its block of 16, chunk slot pslot
+    const int prow = lane >> 4, pslot = lane & 15;
+    const float* qsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = 16 * w + 4 * j + prow;
+        const int qrow = nq > 0 ? qm[sl < nq ? sl : 0] : 0;
+        qsrc[j] = a.Qp + (int64_t)qrow * ld + ((pslot ^ (4 * j + prow)) << 2);
+    }
+    char* ringb = smem + LG_LDS_RING;
+    char* nrm = smem + LG_LDS_NORMS;
+    // The request of one stage is cut into four quarters (row piece j + query piece j) that the main loop places between its
+    // MFMA groups: with one wave per SIMD nothing else covers the issue cost of an LDS-DMA piece (~60 cycles each).  The row
+    // addresses of a tile are formed once, when its first chunk is requested.
+    int iss = 0, iss_tile = 0, iss_kc = 0, iss_slot = 0;
+    const float* rsrc[4];
+    auto issue_quarter = [&](int j) {
+        char* dst = ringb + iss_slot * LG_STAGE_BYTES;
+        if (iss_kc == 0) {
+            const int64_t row0 = first + (int64_t)iss_tile * LG_ROWS + 16 * w;
+            if (j == 0) {  // this wave's 16 row norms (lanes 0-15) and reported ids (lanes 16-31): older than the tile's data
+                int64_t rr = row0 + r16;
+                rr = rr > end - 1 ? end - 1 : rr;
+                const float* nsrc = (a.perm && (lane & 48) == 16) ? reinterpret_cast<const float*>(a.perm + rr) : a.xnorm + rr;
+                __builtin_amdgcn_global_load_lds((gbl_vptr)nsrc, (lds_vptr)(nrm + ((iss_tile & (LG_NORM_SLOTS - 1)) * 4 + w) * 256), 4, 0, 0);
+            }
+            const int r = 4 * j + prow;
+            int64_t rr = row0 + r;
+            rr = rr > end - 1 ? end - 1 : rr;
+            rsrc[j] = a.X + rr * (int64_t)ld + ((pslot ^ r) << 2);
+        }
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(rsrc[j] + (iss_kc << 6)), (lds_vptr)(dst + w * 4096 + j * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc[j] + (iss_kc << 6)), (lds_vptr)(dst + 16384 + w * 4096 + j * 1024), 16, 0, 0);
+        if (j == 3) {
+            ++iss;
+            if (++iss_slot == LG_NST) iss_slot = 0;
+            if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
+        }
+    };
+    for (int pre = 0; pre < 2; ++pre)
+        if (pre < total) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) issue_quarter(j);
+        }
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int con_tile = 0, con_kc = 0, con_slot = 0;
+#pragma unroll 1
+    for (int si = 0; si < total; ++si) {
+        // stage si + 1 (if it exists) was requested one iteration ago: 8 pieces, 9 when it opens a tile (the norms piece)
+        if (si + 1 < total) {
+            if (con_kc + 1 == spt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // raw barrier: everyone's pieces of stage si have landed, and everyone is done with stage si - 1, whose slot the requests
+        // below overwrite (a wave's fragment reads have returned before the MFMAs that consumed them were issued)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool more = si + 2 < total;
+        const char* st = ringb + con_slot * LG_STAGE_BYTES;
+        const char* rst = st + r16 * 256;
+        const char* qst = st + 16384 + w * 4096 + r16 * 256;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = ((4 * t + g) ^ r16) << 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(qst + off);
+            f32x4 av[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) av[rb] = *reinterpret_cast<const f32x4*>(rst + rb * 4096 + off);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][c], bv[c], acc[rb], 0, 0, 0);
+                if (c == 1 && more) issue_quarter(t);  // two LDS-DMA pieces in the middle of this group's 16 MFMAs
+            }
+        }
+        if (++con_slot == LG_NST) con_slot = 0;
+        if (++con_kc == spt) {
+            // ---- tile done: this lane holds query slot 16 w + r16, rows rb * 16 + 4 g + {0..3} of the tile
+            const int64_t row0 = first + (int64_t)con_tile * LG_ROWS;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const char* nb = nrm + ((con_tile & (LG_NORM_SLOTS - 1)) * 4 + rb) * 256;
+                const f32x4 xn = *reinterpret_cast<const f32x4*>(nb + g * 16);
+                const u32x4_t pid = *reinterpret_cast<const u32x4_t*>(nb + 64 + g * 16);
+                const uint64_t thr = thr_w[r16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t row = row0 + rb * 16 + 4 * g + c;
+                    const float sc = sc_score<METRIC>(acc[rb][c], xn[c], qn_mine);
+                    const uint64_t key = sc_make_key<METRIC>(sc, a.perm ? pid[c] : (uint32_t)row);
+                    if (myslot < nq && row < end && key < thr) {
+                        // inline asm, as in scan_exact_kernel: a compiler-visible LDS write would drain the LDS-DMA ring first
+                        unsigned pos;
+                        const unsigned cnt_addr = (unsigned)(uintptr_t)(cnt_w + r16), one = 1u;
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(cnt_addr), "v"(one) : "memory");
+                        const unsigned slot_addr = (unsigned)(uintptr_t)(cand_w + r16 * LG_CAP + pos);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(slot_addr), "v"(key) : "memory");
+                    }
+                }
+                acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool full = cnt_w[r16] > (unsigned)(LG_CAP - 16);
+                if (__any(full)) {
+#pragma unroll 1
+                    for (int c = 0; c < 16; ++c)
+                        if (cnt_w[c] > (unsigned)(LG_CAP - 16)) wave_compact(cand_w + c * LG_CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+                }
+            }
+            con_kc = 0;
+            ++con_tile;
+        }
+    }
+    // ---- flush: the wave sorts its 16 slots and writes their k-lists
+    uint64_t* out = a.partial + ((size_t)grp * LG_QW + 16 * w) * (size_t)a.k;
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+        int m = 0;
+        if (16 * w + c < nq) {
+            wave_compact(cand_w + c * LG_CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+            m = (int)cnt_w[c];
+        }
+        for (int e = lane; e < a.k; e += 64) out[(size_t)c * a.k + e] = e < m ? cand_w[c * LG_CAP + e] : SC_KEY_MAX;
+    }
+}
+
+bool sc_scan_listgemm_supported(int ld, int k) { return ld > 0 && (ld % SC_LD_ALIGN) == 0 && k >= 1 && k <= LG_CAP - 16; }
+int sc_scan_listgemm_width(void) { return LG_QW; }
+
+template <int METRIC>
+static void launch_scan_listgemm(const ListGemmArgs& a, int groups, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_listgemm_kernel<METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((scan_listgemm_kernel<METRIC>), dim3((unsigned)groups), dim3(256), LG_LDS_TOTAL, s, a);
+}
+void sc_launch_scan_listgemm(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, int k, int groups,
+                             uint64_t* partial, const uint32_t* perm, const int64_t* seg_rows, const int32_t* qmap, hipStream_t s) {
+    if (groups <= 0) return;
+    ListGemmArgs a;
+    a.X = X; a.xnorm = xnorm; a.ld = ld; a.Qp = Qp; a.qnorm = qnorm; a.k = k; a.partial = partial; a.perm = perm; a.seg_rows = seg_rows; a.qmap = qmap;
+    if (metric == SC_METRIC_L2) launch_scan_listgemm<SC_METRIC_L2>(a, groups, s);
+    else if (metric == SC_METRIC_COSINE) launch_scan_listgemm<SC_METRIC_COSINE>(a, groups, s);
+    else launch_scan_listgemm<SC_METRIC_IP>(a, groups, s);
+}
+
 bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt, int nprobe, int64_t n_rows) {
     if (ld <= 0 || (ld % SC_LD_ALIGN) != 0 || k < 1 || k > 1024 || Q < 1) return false;
     const int cap = ((k + 16 + 63) / 64) * 64;  // >= k + 16, multiple of 64

@@ -65,10 +65,15 @@ def test_build_and_probe_match_oracle(rt, metric):
 
 
 @pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
-def test_listmajor_probe_equals_per_query_probe(rt, metric):
+@pytest.mark.parametrize("wide", [True, False])
+def test_listmajor_probe_equals_per_query_probe(rt, metric, wide, monkeypatch):
     """List-major probing (every probed list streamed once per group of queries that want it) returns bit for bit what
     per-query probing returns: ragged group sizes, lists wanted by more queries than fit one group, lists nobody wants,
-    empty lists, k from 1 to 64, and the CPU restatement agrees."""
+    empty lists, k from 1 to 64, and the CPU restatement agrees.  `wide`: lists wanted by more than 16 queries go to the
+    64-query GEMM-style kernel (k <= 48; remainders and k = 64 stay on the 16-query scan) or, with SC_IVF_WIDE=0, everything
+    runs on the 16-query scan."""
+    if not wide:
+        monkeypatch.setenv("SC_IVF_WIDE", "0")
     X, centers = clustered(30_000, 96, 25, seed=11)  # 25 clusters on 64 lists: some lists end up tiny or empty
     rng = np.random.default_rng(12)
     ix = _native.Index(rt, 96, metric=metric, kind="IVF_FLAT", nlist=64)
@@ -84,7 +89,7 @@ def test_listmajor_probe_equals_per_query_probe(rt, metric):
         ix.set_search_mode("ivf_listmajor")
         d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
         assert ix.last_search_stats()["path"] == "ivf_listmajor"
-        assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (nq, k, nprobe)
+        assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (nq, k, nprobe, wide)
         rd, rr = ref.search(Q, k, nprobe)
         assert np.array_equal(r4, rr) and np.array_equal(bits(d4), bits(rd)), (nq, k, nprobe)
     assert int((sizes == 0).sum()) >= 0  # informational: empty lists are legal and skipped
@@ -94,6 +99,7 @@ def test_listmajor_probe_equals_per_query_probe(rt, metric):
 def test_listmajor_probe_with_streamed_queries(rt, monkeypatch):
     """List-major probing on the streamed-query scan variant (the default from ~1 400 dimensions up, forced here at 96 and
     taken by itself at 2 048): groups of up to 16 queries per list part, same bits as per-query probing."""
+    monkeypatch.setenv("SC_IVF_WIDE", "0")  # the 16-query classes are what this test is about
     for dim, n, ncl, force in ((96, 30_000, 25, True), (2048, 12_000, 20, False)):
         X, centers = clustered(n, dim, ncl, seed=21)
         rng = np.random.default_rng(22)
@@ -113,6 +119,25 @@ def test_listmajor_probe_with_streamed_queries(rt, monkeypatch):
                 monkeypatch.delenv("SC_SCAN_QSTREAM")
             assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (dim, nq, k, nprobe)
         ix.close()
+
+
+def test_listmajor_wide_groups_long_rows(rt):
+    """The 64-query groups at 2 048 dimensions (32 k-chunks per row tile, three-deep ring wrapping many times), list parts that
+    are not multiples of 64 rows, groups of 17 .. 64 queries with narrow remainders next to them, k up to the kernel's 48."""
+    X, centers = clustered(12_000, 2048, 20, seed=31)
+    rng = np.random.default_rng(32)
+    ix = _native.Index(rt, 2048, metric="L2", kind="IVF_FLAT", nlist=32)
+    ix.add(X)
+    ix.train(niter=4)
+    for nq, k, nprobe in ((150, 10, 8), (300, 48, 4), (77, 1, 31)):
+        Q = (centers[rng.integers(0, 20, size=nq)] + 0.4 * rng.standard_normal((nq, 2048))).astype(np.float32)
+        ix.set_search_mode("ivf")
+        d3, r3 = ix.search(Q, k=k, nprobe=nprobe)
+        ix.set_search_mode("ivf_listmajor")
+        d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
+        assert ix.last_search_stats()["path"] == "ivf_listmajor"
+        assert np.array_equal(r3, r4) and np.array_equal(bits(d3), bits(d4)), (nq, k, nprobe)
+    ix.close()
 
 
 def test_recall_and_forced_probe_on_larger_set(rt):
