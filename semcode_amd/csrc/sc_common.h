@@ -91,10 +91,9 @@ void sc_launch_scan_exact(int metric, const float* X, const float* xnorm, int64_
                           const float* qnorm, int Q, int k, const ScanPlan& p, uint64_t* partial, const uint32_t* perm,
                           const int* seg_base, const int64_t* seg_rows, int nprobe, hipStream_t s, const int32_t* qmap = nullptr);
 // scan_exact.hip, wide groups of list-major IVF probing: one workgroup = one list part [seg_rows[2g], seg_rows[2g+1]) x up to
-// sc_scan_listgemm_width() queries (qmap [groups][width], valid slots a prefix, -1 beyond); partial [groups][width][k] sorted keys
+// `width` (32 or 64) queries (qmap [groups][width], valid slots a prefix, -1 beyond); partial [groups][width][k] sorted keys
 bool sc_scan_listgemm_supported(int ld, int k);
-int sc_scan_listgemm_width(void);
-void sc_launch_scan_listgemm(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, int k, int groups,
+void sc_launch_scan_listgemm(int metric, int width, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, int k, int groups,
                              uint64_t* partial, const uint32_t* perm, const int64_t* seg_rows, const int32_t* qmap, hipStream_t s);
 // partial [groups][lists][qt][k] sorted keys -> out_dist [Q,k], out_rows [Q,k]
 // more lists than one LDS tree merge holds (2 * lists * k keys > 128 KiB) are merged in levels whose intermediate k-lists live right

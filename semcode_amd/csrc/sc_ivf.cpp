@@ -493,10 +493,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     }
     // long lists are cut into parts of at most `target` rows (each part its own group) so that no single workgroup streams a
     // 20k-row list while the others idle; a query then merges up to nprobe * maxparts partial lists
-    // Wide groups (scan_listgemm_kernel): a list probed by more than qt queries is cut into chunks of up to 64 queries, each
-    // streamed ONCE with 4 x the arithmetic per row byte (the matrix pipe, not the row stream, bounds it); a remainder of at most
-    // qt queries joins the narrow classes.  SC_IVF_WIDE=0 switches the class off (A/B, tests of the narrow classes).
-    const int qw = sc_scan_listgemm_width();
+    // Wide groups (scan_listgemm_kernel): a list probed by more than qt queries is cut into chunks of up to 64 queries (a last
+    // chunk of 17 .. 32 takes the 32-query form of the kernel: half the time), each streamed ONCE with 2-4 x the arithmetic per row
+    // byte (the matrix pipe, not the row stream, bounds it); a remainder of at most qt queries joins the narrow classes.  SC_IVF_WIDE=0 switches the class off (A/B, tests of the narrow classes).
+    const int qw = 64, qw2 = 32;  // the two group widths of scan_listgemm_kernel
     bool wide_ok = sc_scan_listgemm_supported(ix->ld, k) && qt == 16;
     if (const char* e = getenv("SC_IVF_WIDE"))
         if (e[0] == '0') wide_ok = false;
@@ -505,9 +505,9 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         const int m = start[(size_t)l + 1] - start[(size_t)l];
         const int64_t len = ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
         if (m == 0 || len <= 0) continue;
-        int mw = 0, c = 0;  // wide chunks of this list
-        while (wide_ok && m - c > qt) { ++mw; c += std::min(qw, m - c); }
-        work_rows_w += len * mw;
+        int mw = 0, c = 0;  // wide chunks of this list, in units of a 64-query chunk's time (a 32-query one takes half)
+        while (wide_ok && m - c > qt) { mw += m - c > qw2 ? 2 : 1; c += std::min(qw, m - c); }
+        work_rows_w += len * mw / 2;
         work_rows += len * ((m - c + qt - 1) / qt);
         longest = std::max(longest, len);
     }
@@ -524,12 +524,12 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         maxparts = std::max(1, parts_of(longest));
     }
     const int L = nprobe * maxparts;
-    std::vector<int32_t> src((size_t)Q * L, -1), qmap, qmap_w;
+    std::vector<int32_t> src((size_t)Q * L, -1), qmap, qmap_w, qmap_w2;
     std::vector<int> sb;
-    std::vector<int64_t> sr, sr_w;
+    std::vector<int64_t> sr, sr_w, sr_w2;
     // With the streamed-query scan (long rows, qt = 16) a group of few queries is still better off on the resident variant,
-    // which streams ~30 % faster: groups are numbered in classes -- the wide ones first (below), then those with more queries
-    // than fit resident (qt_res), then the small ones -- and each class gets its own launch.
+    // which streams ~30 % faster: groups are numbered in classes -- the wide ones first (64, then 32 query slots), then those
+    // with more queries than fit resident (qt_res), then the small ones -- and each class gets its own launch.
     ScanPlan plan_res = plan;
     if (plan.qstream && !sc_scan_exact_plan(ix->ld, 16, k, rt->cus, &plan_res, 16, 1)) plan_res = plan;
     int qt_res = plan_res.qstream ? qt : std::min(qt, plan_res.qt);
@@ -539,23 +539,24 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     // round would leave the other CUs idle for its whole length (stable sort: the numbering stays deterministic).
     struct GroupDesc { int l, c, nqg, part; int64_t p0, p1; };
     std::vector<GroupDesc> descs;
-    int G = 0, G_big = 0, Gw = 0;          // narrow groups (G_big of them on the streamed variant), wide groups
-    int64_t lists_w = 0;                    // k-lists of the wide class: they come first in `partial`
-    for (int cls = -1; cls < 2; ++cls) {    // -1 wide, 0 narrow / streamed queries, 1 narrow / resident queries
-        if (cls == 0) lists_w = (int64_t)Gw * qw;
+    int G = 0, G_big = 0, Gw = 0, Gw2 = 0;  // narrow groups (G_big of them on the streamed variant), wide groups of 64 / 32 slots
+    int64_t lists_w = 0;                    // k-lists of the wide classes: they come first in `partial`
+    for (int cls = -2; cls < 2; ++cls) {    // -2 wide 64, -1 wide 32, 0 narrow / streamed queries, 1 narrow / resident queries
+        if (cls == 0) lists_w = (int64_t)Gw * qw + (int64_t)Gw2 * qw2;
         if (cls == 1) G_big = G;
-        if (cls == -1 && !wide_ok) continue;
+        if (cls < 0 && !wide_ok) continue;
         descs.clear();
         for (int l = 0; l < nlist; ++l) {
             const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
             const int m = start[(size_t)l + 1] - start[(size_t)l];
             if (m == 0 || end <= first) continue;  // nobody probes it / empty list
-            // the chunks of this list's queries: wide ones of up to qw while more than qt remain, then narrow ones of up to qt
+            // the chunks of this list's queries: wide ones of up to 64 while more than qt remain (17 .. 32 left: the 32-slot
+            // form), then narrow ones of up to qt
             int c = 0;
             while (c < m) {
                 const bool wide = wide_ok && m - c > qt;
                 const int nqg = std::min(wide ? qw : qt, m - c);
-                const int want = wide ? -1 : (nqg > qt_res ? 0 : 1);
+                const int want = wide ? (nqg > qw2 ? -2 : -1) : (nqg > qt_res ? 0 : 1);
                 if (want == cls) {
                     const int64_t tg = wide ? target_w : target;
                     const int parts = (int)((end - first + tg - 1) / tg);
@@ -569,9 +570,9 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         }
         std::stable_sort(descs.begin(), descs.end(), [](const GroupDesc& x, const GroupDesc& y) { return x.p1 - x.p0 > y.p1 - y.p0; });
         for (const GroupDesc& d : descs) {
-            const int stride = cls < 0 ? qw : qt;
-            const int64_t base = cls < 0 ? (int64_t)Gw * qw : lists_w + (int64_t)G * qt;
-            std::vector<int32_t>& qm = cls < 0 ? qmap_w : qmap;
+            const int stride = cls == -2 ? qw : cls == -1 ? qw2 : qt;
+            const int64_t base = cls == -2 ? (int64_t)Gw * qw : cls == -1 ? (int64_t)Gw * qw + (int64_t)Gw2 * qw2 : lists_w + (int64_t)G * qt;
+            std::vector<int32_t>& qm = cls == -2 ? qmap_w : cls == -1 ? qmap_w2 : qmap;
             for (int sl = 0; sl < stride; ++sl) {
                 if (sl < d.nqg) {
                     const int32_t pair = pair_of[(size_t)start[(size_t)d.l] + d.c + sl];
@@ -583,9 +584,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
                 }
             }
             if (cls < 0) {
-                sr_w.push_back(d.p0);
-                sr_w.push_back(d.p1);
-                ++Gw;
+                std::vector<int64_t>& srw = cls == -2 ? sr_w : sr_w2;
+                srw.push_back(d.p0);
+                srw.push_back(d.p1);
+                if (cls == -2) ++Gw; else ++Gw2;
             } else {
                 sb.push_back(0);
                 sb.push_back((int)((d.p1 - d.p0 + 15) >> 4));
@@ -599,7 +601,8 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     // 3. plan tables -> device (they replace the probe results in the scratch buffer), queries padded + normed
     off = 0;
     const size_t o_src = carve(src.size() * 4), o_qmap = carve((size_t)G * qt * 4 + 16), o_sb = carve((size_t)G * 2 * 4 + 16),
-                 o_sr = carve((size_t)G * 2 * 8 + 16), o_qmap_w = carve((size_t)Gw * qw * 4 + 16), o_sr_w = carve((size_t)Gw * 2 * 8 + 16);
+                 o_sr = carve((size_t)G * 2 * 8 + 16), o_qmap_w = carve((size_t)Gw * qw * 4 + 16), o_sr_w = carve((size_t)Gw * 2 * 8 + 16),
+                 o_qmap_w2 = carve((size_t)Gw2 * qw2 * 4 + 16), o_sr_w2 = carve((size_t)Gw2 * 2 * 8 + 16);
     st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, off);
     if (st) return st;
     b = (char*)ix->ivf_scratch;
@@ -613,6 +616,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
         SC_HIP(hipMemcpyAsync(b + o_qmap_w, qmap_w.data(), (size_t)Gw * qw * 4, hipMemcpyHostToDevice, s));
         SC_HIP(hipMemcpyAsync(b + o_sr_w, sr_w.data(), (size_t)Gw * 2 * 8, hipMemcpyHostToDevice, s));
     }
+    if (Gw2 > 0) {
+        SC_HIP(hipMemcpyAsync(b + o_qmap_w2, qmap_w2.data(), (size_t)Gw2 * qw2 * 4, hipMemcpyHostToDevice, s));
+        SC_HIP(hipMemcpyAsync(b + o_sr_w2, sr_w2.data(), (size_t)Gw2 * 2 * 8, hipMemcpyHostToDevice, s));
+    }
     st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
     if (st) return st;
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
@@ -624,8 +631,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     // the long ones
     hipEvent_t e0, e1;
     sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-    sc_launch_scan_listgemm((int)ix->metric, ix->X, ix->xnorm, ix->ld, ix->qpad, ix->qnorm, k, Gw, ix->partial, ix->perm,
+    sc_launch_scan_listgemm((int)ix->metric, qw, ix->X, ix->xnorm, ix->ld, ix->qpad, ix->qnorm, k, Gw, ix->partial, ix->perm,
                             (const int64_t*)(b + o_sr_w), (const int32_t*)(b + o_qmap_w), s);
+    sc_launch_scan_listgemm((int)ix->metric, qw2, ix->X, ix->xnorm, ix->ld, ix->qpad, ix->qnorm, k, Gw2, ix->partial + (size_t)Gw * qw * k, ix->perm,
+                            (const int64_t*)(b + o_sr_w2), (const int32_t*)(b + o_qmap_w2), s);
     for (int cls = 0; cls < 2; ++cls)
       for (int g0 = cls ? G_big : 0, hi = cls ? G : G_big; g0 < hi; g0 += 65535) {
         const int gn = std::min(65535, hi - g0);
@@ -649,10 +658,12 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
             streamed += (double)(sr[g + 1] - sr[g]);
             if ((int)(g / 2) < G_big) streamed_big += (double)(sr[g + 1] - sr[g]);
         }
-        double streamed_wide = 0.0;
+        double streamed_wide = 0.0, streamed_wide2 = 0.0;
         for (size_t g = 0; g < sr_w.size(); g += 2) streamed_wide += (double)(sr_w[g + 1] - sr_w[g]);
-        streamed += streamed_wide;
-        fprintf(stderr, "[ivf list-major] wide groups (<= %d queries each): %d = %.1f GB\n", qw, Gw, streamed_wide * (double)ix->ld * 4.0 / 1e9);
+        for (size_t g = 0; g < sr_w2.size(); g += 2) streamed_wide2 += (double)(sr_w2[g + 1] - sr_w2[g]);
+        streamed += streamed_wide + streamed_wide2;
+        fprintf(stderr, "[ivf list-major] wide groups: %d of <= 64 queries = %.1f GB, %d of <= 32 = %.1f GB\n", Gw, streamed_wide * (double)ix->ld * 4.0 / 1e9, Gw2,
+                streamed_wide2 * (double)ix->ld * 4.0 / 1e9);
         streamed *= (double)ix->ld * 4.0;
         streamed_big *= (double)ix->ld * 4.0;
         const double t_scan = since() - t_plan;
@@ -661,9 +672,10 @@ sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32
     }
     ix->last_path = 4;
     ix->last_probed_lists = nprobe;
-    ix->last_groups = G + Gw;
+    ix->last_groups = G + Gw + Gw2;
     for (size_t g = 0; g < sr.size(); g += 2) ix->last_streamed_rows += sr[g + 1] - sr[g];
     for (size_t g = 0; g < sr_w.size(); g += 2) ix->last_streamed_rows += sr_w[g + 1] - sr_w[g];
+    for (size_t g = 0; g < sr_w2.size(); g += 2) ix->last_streamed_rows += sr_w2[g + 1] - sr_w2[g];
     for (int l = 0; l < nlist; ++l)
         if (start[(size_t)l + 1] > start[(size_t)l]) ix->last_unique_rows += ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
     return SC_OK;

@@ -100,6 +100,22 @@ __host__ __device__ static inline ScanLds scan_lds_layout(int ld, int qt, int ca
 // refresh the pruning threshold.  Executed by one whole wave; all traffic through volatile LDS.
 static __device__ __forceinline__ void wave_compact(lds_u64p cand, lds_u64p tmp, lds_u32p cnt, lds_u64p thr, int k, int lane) {
     const int n = (int)*cnt;
+    if (n <= 64) {
+        // one key per lane, ranked against the others by lane broadcasts (v_readlane): no LDS traffic in the n-step loop.  The LDS
+        // form below costs a dependent ds_read_b64 per step; with the wide IVF groups restarting their thresholds per list part
+        // it was a quarter of scan_listgemm_kernel's time.
+        const uint64_t key = lane < n ? cand[lane] : SC_KEY_MAX;
+        const unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint64_t kj = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)khi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)klo, j);
+            rank += kj < key ? 1 : 0;
+        }
+        if (lane < n && rank < k) cand[rank] = key;  // keys are unique (row id in the low word): ranks are a permutation
+        if (n >= k && lane < n && rank == k - 1) *thr = key;
+        if (lane == 0) *cnt = (unsigned)(n < k ? n : k);
+        return;
+    }
     for (int e = lane; e < n; e += 64) {
         const uint64_t key = cand[e];
         int rank = 0;
@@ -376,22 +392,31 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ wide groups: one list part x up to 64 queries per workgroup
+// ------------------------------------------------------------------ wide groups: one list part x 32 or 64 queries per workgroup
 // List-major IVF probing streams a list once per GROUP of queries that probe it.  With 16 queries per group the scan above is
 // bound by its LDS-DMA row stream (4.8-5.1 TB/s at 3 072 dimensions) while the matrix pipe idles (16 MFMAs = 512 cycles per 4 KiB
-// row stage, 28 % busy), and a popular list is streamed again and again: config 5 reads 271 GB for 37.8 GB of distinct lists
-// (profiles/r2i_bench.json.log).  This kernel is the same arithmetic organised as a GEMM: a workgroup takes 64 rows x 64 queries
-// per k-chunk of 64 floats -- rows AND queries staged through a three-deep LDS ring by LDS-DMA (32 KiB per stage, the XOR swizzle
-// of the scan above), one raw barrier per k-chunk -- and wave w multiplies all 64 rows by ITS 16 queries (4 accumulators, 64
-// MFMAs = 2 048 cycles per stage): four times the arithmetic per streamed row byte, so the matrix pipe becomes the bound and a
-// list wanted by 64 queries is streamed once.  Per (row, query) the MFMA chain is the canonical one (k-chunks in order, t then c
-// inside), so scores are bit-identical to scan_exact_kernel.  Candidate lists are wave-private (a wave owns its 16 query slots
-// for every row of the group): no cross-wave merge, the wave writes its slots' sorted k-lists itself.
+// row stage, 28 % busy), and a popular list is streamed again and again: config 5 read 271 GB for 37.8 GB of distinct lists
+// (profiles/r2i_bench.json.log).  This kernel is the same arithmetic organised as a GEMM: a workgroup takes 64 rows x 16 QB
+// queries (QB = 2 or 4 query blocks) per k-chunk of 64 floats -- rows AND queries staged through a three-deep LDS ring by LDS-DMA
+// (16 + 4 QB KiB per stage, the XOR swizzle of the scan above), one raw barrier per k-chunk -- and wave w multiplies the 16 QB
+// rows of its row group by the 16 queries of its query block (QB accumulators, 16 QB MFMAs per stage): QB times the arithmetic
+// per streamed row byte, so a list wanted by 64 queries is streamed once.  Per (row, query) the MFMA chain is the canonical one
+// (k-chunks in order, t then c inside), so scores are bit-identical to scan_exact_kernel.  Candidate lists are wave-private (16
+// query slots x the rows of the wave's row group); the 4 / QB waves that share a query block merge their sorted lists at the end
+// (nothing to merge at QB = 4).
+// Measured (2M x 3072, nlist 1024, 1 024 queries x nprobe 64, scripts/ivf_wide_ab.py; gpurun_out/ivf_wide_ab*.log): list-major
+// probing 40.1 -> 21.8 ms, of which this kernel takes 14.7 ms for 41.9 GB of rows x 64 query slots.  Compile-time ablations of it
+// on one box: without the LDS-DMA requests 12.0 ms (MFMAs + candidate handling; 64 MFMAs x 32 cycles per stage put the floor at
+// 10.2 ms at 2.0 GHz), requests and barriers alone 7.7 ms: it runs within ~20 % of the f32 matrix rate, which is why none of these
+// moved it: spreading the requests between the MFMAs branch-free (22.9 -> 22.7 ms end to end, kept), taking the queries out of the
+// LDS-DMA stream (each lane loading its own B fragments into registers and parking them in wave-private LDS: 23.5 ms, dropped), a
+// register-only rank sort for the candidate lists (wave_compact above: +-0, kept), two waves per SIMD (22.9 -> 21.8 ms, kept
+// where the lists fit: k <= 32).  What is left is arithmetic on empty query slots (groups of 33 .. 63 queries) and the 16-query
+// classes next to it.
 #define LG_ROWS 64
-#define LG_QW 64
 #define LG_NST 3
-#define LG_STAGE_BYTES 32768  // [4 row blocks of 16 x 256 B | 4 query blocks of 16 x 256 B]
-#define LG_CAP 64             // candidates per query slot: k <= LG_CAP - 16 (a row block appends at most 16 per slot)
+// candidates per (wave, query slot): k <= cap - 16 (a row block appends at most 16 per slot); 64 with 4 waves, 48 with 8 (LDS)
+#define LG_CAP(NW) ((NW) == 8 ? 48 : 64)
 #define LG_NORM_SLOTS 4
 
 struct ListGemmArgs {
@@ -401,130 +426,165 @@ struct ListGemmArgs {
     const float* Qp;        // padded queries [Q][ld]
     const float* qnorm;     // [Q]
     int k;
-    uint64_t* partial;      // [groups][LG_QW][k] sorted keys
+    uint64_t* partial;      // [groups][16 QB][k] sorted keys
     const uint32_t* perm;   // stored position -> reported row id, or NULL
     const int64_t* seg_rows;  // [groups][2] = {first, end} stored positions of the group's list part
-    const int32_t* qmap;      // [groups][LG_QW] query rows, valid slots a prefix, -1 beyond
+    const int32_t* qmap;      // [groups][16 QB] query rows, valid slots a prefix, -1 beyond
 };
-#define LG_LDS_RING 0
-#define LG_LDS_NORMS (LG_NST * LG_STAGE_BYTES)
-#define LG_LDS_THR (LG_LDS_NORMS + LG_NORM_SLOTS * 4 * 256)
-#define LG_LDS_CNT (LG_LDS_THR + LG_QW * 8)
-#define LG_LDS_CAND (LG_LDS_CNT + LG_QW * 4)
-#define LG_LDS_TMP (LG_LDS_CAND + LG_QW * LG_CAP * 8)
-#define LG_LDS_TOTAL (LG_LDS_TMP + SCAN_WAVES * LG_CAP * 8)
+template <int QB, int NW>
+struct LgLds {
+    static constexpr unsigned stage = 16384u + 4096u * QB;
+    static constexpr unsigned ring = 0;
+    static constexpr unsigned norms = LG_NST * stage;
+    static constexpr unsigned thr = norms + LG_NORM_SLOTS * 4 * 256;
+    static constexpr unsigned cnt = thr + NW * 16 * 8;
+    static constexpr unsigned cand = cnt + NW * 16 * 4;
+    static constexpr unsigned tmp = cand + NW * 16 * LG_CAP(NW) * 8;
+    static constexpr unsigned total = tmp + NW * LG_CAP(NW) * 8;
+};
 
-template <int METRIC>
-__global__ __launch_bounds__(256) void scan_listgemm_kernel(ListGemmArgs a) {
+// NW waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: one wave's barrier wait and fragment reads run under the other's
+// MFMAs; candidate lists of 48 keys, so k <= 32)
+template <int METRIC, int QB, int NW>
+__global__ __launch_bounds__(NW * 64) void scan_listgemm_kernel(ListGemmArgs a) {
+    using L = LgLds<QB, NW>;
+    constexpr int CAP = LG_CAP(NW);
+    constexpr int QW = 16 * QB;       // query slots of the group
+    constexpr int RG = NW / QB;       // row groups (waves per query block)
+    constexpr int RBW = 4 / RG;       // 16-row blocks per wave
+    constexpr int RP = 16 / NW;       // row pieces (1 KiB = 4 rows) a wave requests per stage
+    constexpr int QP = 4 * QB / NW;   // query pieces a wave requests per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = w % QB, rg = w / QB;  // this wave: query block qb x row blocks [RBW rg, RBW (rg + 1)) of every tile
     const int r16 = lane & 15, g = lane >> 4;
     const int grp = blockIdx.x;
     const int ld = a.ld, spt = ld >> 6;
     const int64_t first = a.seg_rows[2 * (size_t)grp], end = a.seg_rows[2 * (size_t)grp + 1];
     const int ntile = (int)((end - first + LG_ROWS - 1) / LG_ROWS);
     const int total = ntile * spt;
-    const int32_t* qm = a.qmap + (size_t)grp * LG_QW;
-    const int nq = __popcll(__ballot(qm[lane] >= 0));  // valid slots are a prefix
-    // wave-private selection state of slots 16 w .. 16 w + 15
-    lds_u64p thr_w = (lds_u64p)(smem + LG_LDS_THR) + w * 16;
-    lds_u32p cnt_w = (lds_u32p)(smem + LG_LDS_CNT) + w * 16;
-    lds_u64p cand_w = (lds_u64p)(smem + LG_LDS_CAND) + (size_t)w * 16 * LG_CAP;
-    lds_u64p tmp_w = (lds_u64p)(smem + LG_LDS_TMP) + w * LG_CAP;
+    const int32_t* qm = a.qmap + (size_t)grp * QW;
+    const int nq = __popcll(__ballot(lane < QW && qm[lane < QW ? lane : 0] >= 0));  // valid slots are a prefix
+    // wave-private selection state: 16 query slots
+    lds_u64p thr_w = (lds_u64p)(smem + L::thr) + w * 16;
+    lds_u32p cnt_w = (lds_u32p)(smem + L::cnt) + w * 16;
+    lds_u64p cand_w = (lds_u64p)(smem + L::cand) + (size_t)w * 16 * CAP;
+    lds_u64p tmp_w = (lds_u64p)(smem + L::tmp) + w * CAP;
     if (lane < 16) {
         thr_w[lane] = SC_KEY_MAX;
         cnt_w[lane] = 0u;
     }
-    const int myslot = 16 * w + r16;
+    const int myslot = 16 * qb + r16;
     const float qn_mine = myslot < nq ? a.qnorm[qm[myslot]] : 1.0f;
 
-    // ---- LDS-DMA geometry: piece j of this wave = 4 rows (or query slots) 4 j + prow of its block of 16, chunk slot pslot
+    // ---- LDS-DMA geometry.  The 16 row pieces of a stage (piece P = rows 4 (P % 4) + prow of block P / 4) are dealt out RP per
+    // wave, P = w RP + i; the 4 QB query pieces QP per wave the same way.
     const int prow = lane >> 4, pslot = lane & 15;
-    const float* qsrc[4];
+    const float* qsrc[QP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int sl = 16 * w + 4 * j + prow;
+    for (int i = 0; i < QP; ++i) {
+        const int p = w * QP + i, r = 4 * (p & 3) + prow, sl = 16 * (p >> 2) + r;
         const int qrow = nq > 0 ? qm[sl < nq ? sl : 0] : 0;
-        qsrc[j] = a.Qp + (int64_t)qrow * ld + ((pslot ^ (4 * j + prow)) << 2);
+        qsrc[i] = a.Qp + (int64_t)qrow * ld + ((pslot ^ r) << 2);
     }
-    char* ringb = smem + LG_LDS_RING;
-    char* nrm = smem + LG_LDS_NORMS;
-    // The request of one stage is cut into four quarters (row piece j + query piece j) that the main loop places between its
-    // MFMA groups: with one wave per SIMD nothing else covers the issue cost of an LDS-DMA piece (~60 cycles each).  The row
-    // addresses of a tile are formed once, when its first chunk is requested.
-    int iss = 0, iss_tile = 0, iss_kc = 0, iss_slot = 0;
-    const float* rsrc[4];
+    char* ringb = smem + L::ring;
+    char* nrm = smem + L::norms;
+    // Row addresses are kept per piece and advanced by one tile (64 rows) when a tile's first chunk is requested -- no multiply and,
+    // apart from the norms piece that opens a tile, no branch in the request code, so that hipcc can spread it between the MFMAs;
+    // rows past the end of the part are clamped to its last row through the pointer (their scores are dropped by row < end).
+    int iss_tile = 0, iss_kc = 0, iss_slot = 0;
+    const char* rsrc[RP];
+    const char* rlast[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int P = w * RP + i, r = 4 * (P & 3) + prow;
+        rlast[i] = reinterpret_cast<const char*>(a.X + (end - 1) * (int64_t)ld + ((pslot ^ r) << 2));
+        const int64_t rr = first + 16 * (P >> 2) + r - LG_ROWS;  // one tile before the first: the first request advances it
+        rsrc[i] = reinterpret_cast<const char*>(a.X + rr * (int64_t)ld + ((pslot ^ r) << 2));
+    }
+    const int64_t tile_bytes = (int64_t)LG_ROWS * ld * 4;
+    // The request of one stage is cut into four quarters that the main loop places between its MFMA groups: quarter j carries row
+    // piece j (while j < RP) and query piece j - (4 - QP) (the last QP quarters), the first one also the norms piece of a new tile
+    // (waves 0 .. 3: block w).  Stages are requested unconditionally, two past the last real one included (clamped rows into ring
+    // slots that are dead by then; the flush's barrier waits for them): no branch, and one wait count for every stage.
     auto issue_quarter = [&](int j) {
-        char* dst = ringb + iss_slot * LG_STAGE_BYTES;
-        if (iss_kc == 0) {
-            const int64_t row0 = first + (int64_t)iss_tile * LG_ROWS + 16 * w;
-            if (j == 0) {  // this wave's 16 row norms (lanes 0-15) and reported ids (lanes 16-31): older than the tile's data
-                int64_t rr = row0 + r16;
-                rr = rr > end - 1 ? end - 1 : rr;
-                const float* nsrc = (a.perm && (lane & 48) == 16) ? reinterpret_cast<const float*>(a.perm + rr) : a.xnorm + rr;
-                __builtin_amdgcn_global_load_lds((gbl_vptr)nsrc, (lds_vptr)(nrm + ((iss_tile & (LG_NORM_SLOTS - 1)) * 4 + w) * 256), 4, 0, 0);
-            }
-            const int r = 4 * j + prow;
-            int64_t rr = row0 + r;
+        char* dst = ringb + iss_slot * L::stage;
+        if (j == 0 && iss_kc == 0 && w < 4) {  // block w's 16 row norms (lanes 0-15) and reported ids (lanes 16-31): older than the tile's data
+            int64_t rr = first + (int64_t)iss_tile * LG_ROWS + 16 * w + r16;
             rr = rr > end - 1 ? end - 1 : rr;
-            rsrc[j] = a.X + rr * (int64_t)ld + ((pslot ^ r) << 2);
+            const float* nsrc = (a.perm && (lane & 48) == 16) ? reinterpret_cast<const float*>(a.perm + rr) : a.xnorm + rr;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)nsrc, (lds_vptr)(nrm + ((iss_tile & (LG_NORM_SLOTS - 1)) * 4 + w) * 256), 4, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((gbl_vptr)(rsrc[j] + (iss_kc << 6)), (lds_vptr)(dst + w * 4096 + j * 1024), 16, 0, 2);
-        __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc[j] + (iss_kc << 6)), (lds_vptr)(dst + 16384 + w * 4096 + j * 1024), 16, 0, 0);
+        if (j < RP) {
+            const int i = j < RP ? j : 0, P = w * RP + i;
+            const char* adv = rsrc[i] + (iss_kc == 0 ? tile_bytes : (int64_t)0);
+            rsrc[i] = adv;
+            const char* src = (adv > rlast[i] ? rlast[i] : adv) + ((int64_t)iss_kc << 8);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(dst + P * 1024), 16, 0, 2);
+        }
+        if (j >= 4 - QP) {
+            const int i = j >= 4 - QP ? j - (4 - QP) : 0, p = w * QP + i;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(qsrc[i] + (iss_kc << 6)), (lds_vptr)(dst + 16384 + p * 1024), 16, 0, 0);
+        }
         if (j == 3) {
-            ++iss;
             if (++iss_slot == LG_NST) iss_slot = 0;
             if (++iss_kc == spt) { iss_kc = 0; ++iss_tile; }
         }
     };
-    for (int pre = 0; pre < 2; ++pre)
-        if (pre < total) {
+    for (int pre = 0; pre < 2; ++pre) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) issue_quarter(j);
-        }
+        for (int j = 0; j < 4; ++j) issue_quarter(j);
+    }
 
-    f32x4 acc[4];
+    f32x4 acc[RBW];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RBW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int con_tile = 0, con_kc = 0, con_slot = 0;
 #pragma unroll 1
     for (int si = 0; si < total; ++si) {
-        // stage si + 1 (if it exists) was requested one iteration ago: 8 pieces, 9 when it opens a tile (the norms piece)
-        if (si + 1 < total) {
-            if (con_kc + 1 == spt) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage si + 1 is the younger one in flight: RP + QP pieces, one more when it opens a tile (the norms piece; waves 0 .. 3)
+        {
+            constexpr int N = RP + QP;
+            static_assert(N == 8 || N == 6 || N == 4, "wait counts below");
+            if (con_kc + 1 == spt && w < 4) {
+                if (N == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if (N == 6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
         }
         // raw barrier: everyone's pieces of stage si have landed, and everyone is done with stage si - 1, whose slot the requests
         // below overwrite (a wave's fragment reads have returned before the MFMAs that consumed them were issued)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const bool more = si + 2 < total;
-        const char* st = ringb + con_slot * LG_STAGE_BYTES;
-        const char* rst = st + r16 * 256;
-        const char* qst = st + 16384 + w * 4096 + r16 * 256;
+        const char* st = ringb + con_slot * L::stage;
+        const char* rst = st + (rg * RBW) * 4096 + r16 * 256;
+        const char* qst = st + 16384 + qb * 4096 + r16 * 256;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int off = ((4 * t + g) ^ r16) << 4;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(qst + off);
-            f32x4 av[4];
+            f32x4 av[RBW];
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) av[rb] = *reinterpret_cast<const f32x4*>(rst + rb * 4096 + off);
+            for (int i = 0; i < RBW; ++i) av[i] = *reinterpret_cast<const f32x4*>(rst + i * 4096 + off);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][c], bv[c], acc[rb], 0, 0, 0);
-                if (c == 1 && more) issue_quarter(t);  // two LDS-DMA pieces in the middle of this group's 16 MFMAs
+                for (int i = 0; i < RBW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][c], bv[c], acc[i], 0, 0, 0);
+                if (c == 1) issue_quarter(t);  // LDS-DMA pieces in the middle of this group's MFMAs
             }
         }
         if (++con_slot == LG_NST) con_slot = 0;
         if (++con_kc == spt) {
-            // ---- tile done: this lane holds query slot 16 w + r16, rows rb * 16 + 4 g + {0..3} of the tile
+            // ---- tile done: this lane holds query slot 16 qb + r16, rows (rg RBW + i) * 16 + 4 g + {0..3} of the tile
             const int64_t row0 = first + (int64_t)con_tile * LG_ROWS;
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
+            for (int i = 0; i < RBW; ++i) {
+                const int rb = rg * RBW + i;
                 const char* nb = nrm + ((con_tile & (LG_NORM_SLOTS - 1)) * 4 + rb) * 256;
                 const f32x4 xn = *reinterpret_cast<const f32x4*>(nb + g * 16);
                 const u32x4_t pid = *reinterpret_cast<const u32x4_t*>(nb + 64 + g * 16);
@@ -532,62 +592,92 @@ __global__ __launch_bounds__(256) void scan_listgemm_kernel(ListGemmArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int64_t row = row0 + rb * 16 + 4 * g + c;
-                    const float sc = sc_score<METRIC>(acc[rb][c], xn[c], qn_mine);
+                    const float sc = sc_score<METRIC>(acc[i][c], xn[c], qn_mine);
                     const uint64_t key = sc_make_key<METRIC>(sc, a.perm ? pid[c] : (uint32_t)row);
                     if (myslot < nq && row < end && key < thr) {
                         // inline asm, as in scan_exact_kernel: a compiler-visible LDS write would drain the LDS-DMA ring first
                         unsigned pos;
                         const unsigned cnt_addr = (unsigned)(uintptr_t)(cnt_w + r16), one = 1u;
                         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(cnt_addr), "v"(one) : "memory");
-                        const unsigned slot_addr = (unsigned)(uintptr_t)(cand_w + r16 * LG_CAP + pos);
+                        const unsigned slot_addr = (unsigned)(uintptr_t)(cand_w + r16 * CAP + pos);
                         asm volatile("ds_write_b64 %0, %1" ::"v"(slot_addr), "v"(key) : "memory");
                     }
                 }
-                acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool full = cnt_w[r16] > (unsigned)(LG_CAP - 16);
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool full = cnt_w[r16] > (unsigned)(CAP - 16);
                 if (__any(full)) {
 #pragma unroll 1
                     for (int c = 0; c < 16; ++c)
-                        if (cnt_w[c] > (unsigned)(LG_CAP - 16)) wave_compact(cand_w + c * LG_CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+                        if (cnt_w[c] > (unsigned)(CAP - 16)) wave_compact(cand_w + c * CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
                 }
             }
             con_kc = 0;
             ++con_tile;
         }
     }
-    // ---- flush: the wave sorts its 16 slots and writes their k-lists
-    uint64_t* out = a.partial + ((size_t)grp * LG_QW + 16 * w) * (size_t)a.k;
+    // ---- flush: every wave sorts its 16 slots; the RG waves of a query block then merge their lists per slot (rank among the
+    // union, keys are unique) and write ONE sorted k-list: partial[grp][slot][k]
 #pragma unroll 1
-    for (int c = 0; c < 16; ++c) {
-        int m = 0;
-        if (16 * w + c < nq) {
-            wave_compact(cand_w + c * LG_CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
-            m = (int)cnt_w[c];
+    for (int c = 0; c < 16; ++c) wave_compact(cand_w + c * CAP, tmp_w, cnt_w + c, thr_w + c, a.k, lane);
+    __syncthreads();  // (also waits for the two stages requested past the end)
+    uint64_t* out = a.partial + (size_t)grp * QW * (size_t)a.k;
+    lds_u64p cand_all = (lds_u64p)(smem + L::cand);
+    lds_u32p cnt_all = (lds_u32p)(smem + L::cnt);
+    // slot 16 b + c is shared by waves b + QB v (v < RG): the 16 slots of block qb are dealt out over its RG waves
+#pragma unroll 1
+    for (int c = rg; c < 16; c += RG) {
+        const int slot = 16 * qb + c;
+        int m[RG], tot = 0;
+#pragma unroll
+        for (int v = 0; v < RG; ++v) {
+            m[v] = slot < nq ? (int)cnt_all[(qb + QB * v) * 16 + c] : 0;
+            tot += m[v];
         }
-        for (int e = lane; e < a.k; e += 64) out[(size_t)c * a.k + e] = e < m ? cand_w[c * LG_CAP + e] : SC_KEY_MAX;
+        for (int e = lane; e < tot; e += 64) {
+            int v = 0, idx = e;
+            while (idx >= m[v]) { idx -= m[v]; ++v; }
+            const uint64_t key = cand_all[((size_t)(qb + QB * v) * 16 + c) * CAP + idx];
+            int rank = 0;
+#pragma unroll
+            for (int u = 0; u < RG; ++u)
+                for (int j = 0; j < m[u]; ++j) rank += (cand_all[((size_t)(qb + QB * u) * 16 + c) * CAP + j] < key) ? 1 : 0;
+            if (rank < a.k) out[(size_t)slot * a.k + rank] = key;
+        }
+        const int have = tot < a.k ? tot : a.k;
+        for (int e = have + lane; e < a.k; e += 64) out[(size_t)slot * a.k + e] = SC_KEY_MAX;
     }
 }
 
-bool sc_scan_listgemm_supported(int ld, int k) { return ld > 0 && (ld % SC_LD_ALIGN) == 0 && k >= 1 && k <= LG_CAP - 16; }
-int sc_scan_listgemm_width(void) { return LG_QW; }
+bool sc_scan_listgemm_supported(int ld, int k) { return ld > 0 && (ld % SC_LD_ALIGN) == 0 && k >= 1 && k <= LG_CAP(4) - 16; }
 
-template <int METRIC>
+template <int METRIC, int QB, int NW>
 static void launch_scan_listgemm(const ListGemmArgs& a, int groups, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_listgemm_kernel<METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_listgemm_kernel<METRIC, QB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((scan_listgemm_kernel<METRIC>), dim3((unsigned)groups), dim3(256), LG_LDS_TOTAL, s, a);
+    constexpr unsigned lds = LgLds<QB, NW>::total;
+    hipLaunchKernelGGL((scan_listgemm_kernel<METRIC, QB, NW>), dim3((unsigned)groups), dim3(NW * 64), lds, s, a);
 }
-void sc_launch_scan_listgemm(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, int k, int groups,
+template <int METRIC>
+static void launch_scan_listgemm_m(const ListGemmArgs& a, int width, int groups, hipStream_t s) {
+    // 64-query groups: two waves per SIMD where the candidate lists fit (k <= 32); SC_IVF_WAVES=4 forces one per SIMD (A/B)
+    static const char* env = getenv("SC_IVF_WAVES");
+    const bool eight = a.k <= LG_CAP(8) - 16 && !(env && env[0] == '4');
+    if (width == 64 && eight) launch_scan_listgemm<METRIC, 4, 8>(a, groups, s);
+    else if (width == 64) launch_scan_listgemm<METRIC, 4, 4>(a, groups, s);
+    else launch_scan_listgemm<METRIC, 2, 4>(a, groups, s);
+}
+// width: 32 or 64 query slots per group
+void sc_launch_scan_listgemm(int metric, int width, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, int k, int groups,
                              uint64_t* partial, const uint32_t* perm, const int64_t* seg_rows, const int32_t* qmap, hipStream_t s) {
     if (groups <= 0) return;
     ListGemmArgs a;
     a.X = X; a.xnorm = xnorm; a.ld = ld; a.Qp = Qp; a.qnorm = qnorm; a.k = k; a.partial = partial; a.perm = perm; a.seg_rows = seg_rows; a.qmap = qmap;
-    if (metric == SC_METRIC_L2) launch_scan_listgemm<SC_METRIC_L2>(a, groups, s);
-    else if (metric == SC_METRIC_COSINE) launch_scan_listgemm<SC_METRIC_COSINE>(a, groups, s);
-    else launch_scan_listgemm<SC_METRIC_IP>(a, groups, s);
+    if (metric == SC_METRIC_L2) launch_scan_listgemm_m<SC_METRIC_L2>(a, width, groups, s);
+    else if (metric == SC_METRIC_COSINE) launch_scan_listgemm_m<SC_METRIC_COSINE>(a, width, groups, s);
+    else launch_scan_listgemm_m<SC_METRIC_IP>(a, width, groups, s);
 }
 
 bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt, int nprobe, int64_t n_rows) {
