@@ -355,6 +355,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
             // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
             bool g;
             if (I8) {
+                // (__float_as_int, not __builtin_bit_cast(int, acc[ni][mi][r]): hipcc lowers the bit_cast of a vector-ELEMENT lvalue as
+                // element 0 -- the first int8 build tested the wrong accumulators for three queries in four)
                 const int a0 = __float_as_int(acc[ni][mi][0]), a1 = __float_as_int(acc[ni][mi][1]), a2 = __float_as_int(acc[ni][mi][2]),
                           a3 = __float_as_int(acc[ni][mi][3]);
                 g = (a0 >= Ti) | (a1 >= Ti) | (a2 >= Ti) | (a3 >= Ti);
