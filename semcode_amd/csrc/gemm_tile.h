@@ -214,6 +214,12 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 // (MFMAs run on whatever the registers hold: the pure matrix-pipe ceiling of this loop).  Two variants with valid results were
 // A/B-tested on one box and dropped (gpurun_out/r2e: 20.8k -> 20.1k chunks/s each): s_setprio(1) around the MFMA blocks, and the
 // A operand's in-loop LDS-DMA with the nt cache policy.
+// Round 2 (profiles/r2n_gemm_k32_ab.log): this loop serialises more than it overlaps -- at 8k^3 it takes 884 us, its LDS-DMA requests,
+// barriers and fragment reads alone 484, its MFMAs alone 582: one 64 KiB request is in flight between two barriers and its round
+// trip (~1.3 us) exceeds the MFMA time of a K-tile (1.0 us).  A variant with 32-deep K-tiles in four stages (two requests in
+// flight, 64-byte rows read without a swizzle, one barrier per 32 MFMAs) was built and is correct, but its own skeleton is slower
+// (593 us: every 128-byte line is requested twice, twice the barriers): 8k^3 1.31 -> 1.17 PF, encoder 20.1k -> 15.6k chunks/s.
+// Not kept.  Three stages of full 64-deep tiles do not fit 160 KiB next to the epilogue staging.
 // tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
 // reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
 // tile, gemm_bf16.hip) and have it land under those MFMAs.
