@@ -446,12 +446,15 @@ def bench_ivf(ctx, args) -> dict:
     return {"value": Q / step_s, "unit": "queries/s", "ms_per_step": 1e3 * step_s, "recall_at_10": recall, "path": "ivf_listmajor",
             "workload": f"IVF_FLAT nlist={nlist} nprobe={nprobe}, {rows} x {dim} f32 rows (clustered synthetic, device generated), batch-{Q} queries, L2 top-{k}",
             "train_s": t_train, "list_size_min_median_max": [int(sizes.min()), int(np.median(sizes)), int(sizes.max())],
-            "roofline": {"bound": "hbm", "kernel": "scan_exact_kernel (list-major segment mode)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "scan_listgemm_kernel (lists wanted by > 16 queries, 32 / 64 per group) + scan_exact_kernel (segment mode, <= 16 per group)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": unique / kern_s / 1e9 if kern_s else None, "frac": unique / kern_s / 1e9 / HBM_PEAK_GBS if kern_s else None,
                          "algorithmic_bytes_per_step": unique, "streamed_bytes_per_step": streamed, "groups": pst["groups"],
                          "kernel_ms_per_step": k_ms / args.steps if k_n else None,
-                         "note": "algorithmic = bytes of the DISTINCT probed lists (SURVEY 8d config 5); streamed = what the kernel reads "
-                                 "(a list wanted by more than 16 queries is streamed once per group of 16; repeats are mostly served by L2/MALL)"},
+                         "f32_mfma_view": {"algorithmic_flops_per_step": 2.0 * Q * nprobe * (rows / nlist) * dim, "peak_tflops": 157.3,
+                                           "achieved_tflops": 2.0 * Q * nprobe * (rows / nlist) * dim / kern_s / 1e12 if kern_s else None,
+                                           "note": "exact f32 scores of every (query, probed row) pair on v_mfma_f32_16x16x4_f32: the roof that binds once a list is streamed once per 64 queries"},
+                         "note": "algorithmic = bytes of the DISTINCT probed lists (SURVEY 8d config 5); streamed = what the kernels read "
+                                 "(a list is streamed once per group of up to 64 queries that probe it, 16 for the remainders)"},
             "exhaustive": {"ms_per_batch": 1e3 * t_bf, "qps": Q / t_bf, "path": bf_stats["path"], "uncertified": bf_stats["uncertified"]},
             "auto_planner": {"path": auto_path, "ms_per_batch": 1e3 * t_auto}, "single_query_ms": 1e3 * t_one}
 
