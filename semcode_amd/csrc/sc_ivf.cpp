@@ -429,12 +429,23 @@ bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, b
     // list-major streams 5.5 TB/s after 1.5 ms of coarse probe + planning; batched exhaustive 1.0 PFLOP/s + 1 ms; exact
     // scan 6 TB/s per pass of qt queries.
     const double n = (double)ix->n, row_bytes = (double)ix->ld * 4.0, pairs = (double)Q * nprobe;
-    double work_rows = 0.0;
+    // a list expected to be wanted by m queries: chunks of 64 on the GEMM-shaped kernel (f32 MFMA bound: 2 * 64 * ld FLOP per row at
+    // ~100 TFLOP/s, profiles/r2m_kernel_stats.csv), a remainder of <= 16 on the 16-query scan (row stream at 5.5 TB/s)
+    const bool wide_ok = sc_scan_listgemm_supported(ix->ld, k) && plan.qt == 16;
+    const double t_row_narrow = row_bytes / 5.5e12, t_row_wide = 2.0 * 64.0 * (double)ix->ld / 1.0e14;
+    double t_scan = 0.0;
     for (int l = 0; l < ix->nlist_trained; ++l) {
         const double len = (double)(ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l]);
-        if (len > 0) work_rows += len * std::max(1.0, std::ceil(pairs * len / (n * plan.qt)));
+        if (len <= 0) continue;
+        double m = std::max(1.0, std::ceil(pairs * len / n));
+        if (wide_ok && m > plan.qt) {
+            const double chunks = std::floor(m / 64.0), rest = m - 64.0 * chunks;
+            t_scan += len * t_row_wide * (chunks + (rest > plan.qt ? (rest > 32.0 ? 1.0 : 0.5) : 0.0));
+            m = rest > plan.qt ? 0.0 : rest;
+        }
+        t_scan += len * t_row_narrow * std::ceil(m / plan.qt);
     }
-    const double t_lm = work_rows * row_bytes / 5.5e12 + 1.5e-3;
+    const double t_lm = t_scan + 1.5e-3;
     const double t_pass = n * row_bytes / 6.0e12;
     double t_flat;
     if (flat_is_batched) {
