@@ -220,6 +220,16 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 // flight, 64-byte rows read without a swizzle, one barrier per 32 MFMAs) was built and is correct, but its own skeleton is slower
 // (593 us: every 128-byte line is requested twice, twice the barriers): 8k^3 1.31 -> 1.17 PF, encoder 20.1k -> 15.6k chunks/s.
 // Not kept.  Three stages of full 64-deep tiles do not fit 160 KiB next to the epilogue staging.
+// Round 2 (profiles/r2n_gemm_k32_ab.log): at 8k^3 this loop takes 800 us without its epilogue; without its LDS-DMA 655, its MFMAs
+// alone 574 (1.92 PF: the matrix pipe at the clock the part holds under this load), its LDS-DMA requests, barriers and fragment
+// reads alone 477.  The fill is therefore not hidden -- it adds 145 us to the 655 -- although it would fit under them twice over.
+// Two rearrangements were built, are correct on every encoder test, and did not change that: 32-deep K-tiles in four stages (two
+// requests in flight, 64-byte rows read without a swizzle, a barrier per 32 MFMAs: 8k^3 1.31 -> 1.17 PF, encoder 20.1k -> 15.6k
+// chunks/s -- its own skeleton is slower, every 128-byte line being requested twice), and this loop with the request moved to the
+// start of the iteration behind a second barrier (1.5 iterations of lead instead of 1.0: 8k^3 +2 %, FFN2 -2.5 %, encoder -1.3 %).
+// So the stall is neither a lack of requests in flight nor of lead time; what the MFMAs and the LDS-DMA writes share is the LDS
+// itself (192 KiB of fragment reads + 64 KiB of DMA writes per K-tile) and the issue slots of the waves that request the pieces.
+// Neither variant was kept.
 // tail: called by every wave right after the LAST barrier of the loop, before the final 32 MFMAs.  From there on no wave
 // reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
 // tile, gemm_bf16.hip) and have it land under those MFMAs.
