@@ -336,7 +336,7 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     for (int mi = 0; mi < 8; ++mi) {
         const int rl = wm * 128 + mi * 16 + fr;
         const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
-        const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
+        const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;  // exact: the precise test below uses it too
         const float sx = I8 ? q_tf[1280 + rl] : 0.f;  // int8 stage: the integer dot is scaled by s_r s_q
         const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
         // Prefilter: ONE compare per score.  The fast test t <= tf_q is  dot >= (base_r - tf_q) / c_r  with base_r = |x|^2 (L2) or
@@ -344,7 +344,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         // scale (sc_launch_query_i8) -- so the right-hand side differs between this lane's 16 queries only through tf_q, and with
         // tfmax = max of those it is bounded below by a per-row constant.  Anything that passes is tested precisely below.
         float Tlb;
-        if (I8) Tlb = ((METRIC == SC_METRIC_L2 ? xn : 0.f) - tfmax) / (-ar * sq0);
+        // (v_rcp_f32, 1 ulp, instead of an IEEE division: the bound only has to be conservative, and the 4e-6 slack below covers it)
+        if (I8) Tlb = ((METRIC == SC_METRIC_L2 ? xn : 0.f) - tfmax) * __builtin_amdgcn_rcpf(-ar * sq0);
         else Tlb = (METRIC == SC_METRIC_L2) ? 0.5f * (xn - tfmax) : (METRIC == SC_METRIC_COSINE) ? -tfmax / xs : -tfmax;
         Tlb = Tlb - fabsf(Tlb) * 4e-6f - (I8 ? 2.0f : 0.f);  // rounding of this bound itself (the precise test has its own slack)
         int Ti = 0;
