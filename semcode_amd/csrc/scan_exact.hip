@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(ScanArgs a) {
 // Measured (2M x 3072, nlist 1024, 1 024 queries x nprobe 64, scripts/ivf_wide_ab.py; gpurun_out/ivf_wide_ab*.log): list-major
 // probing 40.1 -> 21.8 ms, of which this kernel takes 14.7 ms for 41.9 GB of rows x 64 query slots.  Compile-time ablations of it
 // on one box: without the LDS-DMA requests 12.0 ms (MFMAs + candidate handling; 64 MFMAs x 32 cycles per stage put the floor at
-// 10.2 ms at 2.0 GHz), requests and barriers alone 7.7 ms: it runs within ~20 % of the f32 matrix rate, which is why none of these
-// moved it: spreading the requests between the MFMAs branch-free (22.9 -> 22.7 ms end to end, kept), taking the queries out of the
+// 10.2 ms at 2.0 GHz; PMC: matrix pipe busy 0.61, profiles/r2p_pmc_mfma_ivf.json), requests and barriers alone 7.7 ms.  None of
+// these moved it: spreading the requests between the MFMAs branch-free (22.9 -> 22.7 ms end to end, kept), taking the queries out of the
 // LDS-DMA stream (each lane loading its own B fragments into registers and parking them in wave-private LDS: 23.5 ms, dropped), a
 // register-only rank sort for the candidate lists (wave_compact above: +-0, kept), two waves per SIMD (22.9 -> 21.8 ms, kept
 // where the lists fit: k <= 32).  What is left is arithmetic on empty query slots (groups of 33 .. 63 queries) and the 16-query
