@@ -1,0 +1,155 @@
+"""CPU: the retrieval caller against the pins read from reference
+src/semcode/rag/pipeline.py:93-175: lazy connect and its failure, top_k from rag_max_context_sources, what counts as
+"no results", the document mapping, the score attribute order, embed_query's fallback -- and the batch form against the
+single-question form."""
+import numpy as np
+import pytest
+
+from semcode_amd.embeddings.payload import EmbeddingPayload
+from semcode_amd.services import Retriever, embed_query, hit_to_document
+from semcode_amd.settings import settings
+from semcode_amd.storage import MilvusVectorStore
+from tests.test_host_seams import FakeIndex, payload
+
+
+class WordEmbedder:
+    """4-d toy embeddings: one axis per known word."""
+
+    words = {"alpha": 0, "beta": 1, "gamma": 2, "delta": 3}
+
+    def __init__(self):
+        self.calls = []
+
+    def _vec(self, text):
+        v = np.zeros(4, np.float32)
+        for w in text.split():
+            if w in self.words:
+                v[self.words[w]] += 1.0
+        return v
+
+    def embed_query(self, text):
+        self.calls.append(("embed_query", text))
+        return self._vec(text).tolist()
+
+    def embed_documents(self, texts):
+        self.calls.append(("embed_documents", len(texts)))
+        return [self._vec(t).tolist() for t in texts]
+
+    def embed_documents_array(self, texts):
+        self.calls.append(("embed_documents_array", len(texts)))
+        return np.stack([self._vec(t) for t in texts])
+
+
+def filled_store():
+    s = MilvusVectorStore(dim=4, index_factory=lambda **kw: FakeIndex(kw["dim"]))
+    s.connect()
+    vecs = [[1, 0, 0, 0], [0.8, 0.2, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.9, 0.1], [0, 0, 0, 1], [0.5, 0.5, 0, 0]]
+    s.upsert_embeddings([payload(i, v) for i, v in enumerate(vecs)])
+    return s
+
+
+def test_retrieve_maps_hits_like_the_reference(monkeypatch):
+    monkeypatch.setattr(settings, "rag_max_context_sources", 3)
+    emb, store = WordEmbedder(), filled_store()
+    r = Retriever(emb, store)
+    docs = r.retrieve("alpha")
+    assert [d["path"] for d in docs] == ["src/f0.py", "src/f1.py", "src/f6.py"]  # top_k = 3, best first
+    assert docs[0] == {"repo": "demo", "path": "src/f0.py", "language": "python", "snippet": "text 0", "score": pytest.approx(1.0),
+                       "metadata": docs[0]["metadata"]}
+    assert docs[0]["metadata"]["language"] == "python" and r.last_error is None
+    assert emb.calls == [("embed_query", "alpha")]
+    monkeypatch.setattr(settings, "rag_max_context_sources", 0)  # max(1, ...)
+    assert len(r.retrieve("beta")) == 1
+
+
+def test_embed_query_falls_back_to_embed_documents():
+    class OnlyDocs:
+        def embed_documents(self, texts):
+            return [[float(len(t))] for t in texts]
+
+    assert embed_query(OnlyDocs(), "abcd") == [4.0]
+
+
+def test_failures_yield_empty_lists_and_keep_the_error():
+    class Down:
+        def connect(self):
+            raise ConnectionError("no server")
+
+    r = Retriever(WordEmbedder(), Down())
+    assert r.retrieve("alpha") == [] and isinstance(r.last_error, ConnectionError)
+
+    class Flaky(MilvusVectorStore):
+        def search(self, vector, top_k=10):
+            raise RuntimeError("search failed")
+
+    s = Flaky(dim=4, index_factory=lambda **kw: FakeIndex(kw["dim"]))
+    r = Retriever(WordEmbedder(), s)
+    assert r.retrieve("alpha") == [] and isinstance(r.last_error, RuntimeError)
+
+    class Empty:
+        def connect(self):
+            pass
+
+        def search(self, vector, top_k=10):
+            return []
+
+    r = Retriever(WordEmbedder(), Empty())
+    assert r.retrieve("alpha") == [] and isinstance(r.last_error, ValueError) and str(r.last_error) == "no_results"
+    # a store that connected once is not connected again
+    good = filled_store()
+    calls = []
+    orig = good.connect
+    good.connect = lambda: (calls.append(1), orig())[1]
+    r = Retriever(WordEmbedder(), good)
+    r.retrieve("alpha"); r.retrieve("beta")
+    assert calls == [1] and r.last_error is None
+
+
+def test_hit_to_document_shapes():
+    class E:
+        def __init__(self, d):
+            self.d = d
+
+        def get(self, k):
+            return self.d.get(k)
+
+    class H:
+        pass
+
+    h = H(); h.entity = E({"repo": "r", "path": "p", "language": "c", "text": None, "metadata": None}); h.distance = "0.25"; h.similarity = 9.0
+    assert hit_to_document(h) == {"repo": "r", "path": "p", "language": "c", "snippet": "", "score": 0.25, "metadata": {}}  # distance before similarity
+    h2 = H(); h2.entity = E({}); h2.score = object()  # unconvertible score -> 0.0, and the search for an attribute stops there
+    h2.distance = 3.0
+    assert hit_to_document(h2)["score"] == 0.0
+    h3 = H(); h3.entity = None
+    assert hit_to_document(h3) is None
+    assert hit_to_document(object()) is None
+
+
+def test_retrieve_batch_equals_retrieve_per_question(monkeypatch):
+    monkeypatch.setattr(settings, "rag_max_context_sources", 2)
+    emb, store = WordEmbedder(), filled_store()
+    r = Retriever(emb, store)
+    qs = ["alpha", "gamma delta", "beta", "unknown words only"]
+    single = [r.retrieve(q) for q in qs]
+    emb.calls.clear()
+    batch = r.retrieve_batch(qs)
+    assert batch == single
+    assert emb.calls == [("embed_documents_array", 4)]  # one encoder batch
+    assert r.retrieve_batch([]) == []
+
+    class Plain:  # seams without the array fast paths: falls back to one retrieve per question
+        def __init__(self, s):
+            self.s = s
+
+        def connect(self):
+            pass
+
+        def search(self, vector, top_k=10):
+            return self.s.search(vector, top_k=top_k)
+
+    class PlainEmb:
+        def embed_query(self, t):
+            return emb._vec(t).tolist()
+
+    assert Retriever(PlainEmb(), Plain(store)).retrieve_batch(qs) == single

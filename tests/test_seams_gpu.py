@@ -11,7 +11,7 @@ import pytest
 from semcode_amd.embeddings import EmbeddingPayload, EmbeddingProviderFactory
 from semcode_amd.embeddings.providers import MI355XEmbeddings
 from semcode_amd import _native
-from semcode_amd.services import build_payloads, ingest_chunks
+from semcode_amd.services import Retriever, build_payloads, ingest_chunks
 from semcode_amd.settings import settings
 from semcode_amd.storage import MilvusVectorStore
 
@@ -82,6 +82,33 @@ def test_embed_store_search_round_trip(rt):
     d, r = cos.search_batch(np.asarray([p.vector for p in payloads[:40]], np.float32), top_k=1)
     assert r[:, 0].tolist() == list(range(40))
     cos.close()
+    emb.close()
+
+
+def test_retriever_on_the_device_seams(rt, monkeypatch):
+    """The retrieval caller (pipeline.py:93-175) on the real classes: every chunk, asked for by its own text, comes back first;
+    the batch form (one encoder batch + one batched search) returns what the single-question form returns."""
+    monkeypatch.setattr(settings, "rag_max_context_sources", 4)
+    emb = MI355XEmbeddings(cfg=SMALL, runtime=rt, synth_seed=3, allow_synthetic=True)
+    root = Path("/w/demo")
+    rng = np.random.default_rng(5)
+    vocab = [f"w{j}" for j in range(400)]
+    texts = [" ".join(rng.choice(vocab, size=30)) for _ in range(90)]  # distinct bags of words: a text is its own nearest neighbour
+    chunks = [Chunk(t, root / "pkg" / f"k{i}.py", "python", 1, 3) for i, t in enumerate(texts)]
+    store = MilvusVectorStore(collection_name="test_retrieval", dim=128, metric="COSINE", index_type="FLAT", runtime=rt)
+    r = Retriever(emb, store)  # connects lazily
+    store.connect()
+    store.upsert_embeddings(build_payloads("demo", root, chunks, emb))
+    qs = [texts[i] for i in (0, 17, 55, 89)]
+    single = [r.retrieve(q) for q in qs]
+    for i, docs in zip((0, 17, 55, 89), single):
+        assert len(docs) == 4 and docs[0]["path"] == f"pkg/k{i}.py" and docs[0]["snippet"] == texts[i] and docs[0]["repo"] == "demo"
+        assert all(docs[j]["score"] >= docs[j + 1]["score"] for j in range(3)) and docs[0]["score"] == pytest.approx(1.0, abs=2e-3)  # best first
+    batch = r.retrieve_batch(qs)
+    assert [[d["path"] for d in docs] for docs in batch] == [[d["path"] for d in docs] for docs in single]
+    assert np.allclose([[d["score"] for d in docs] for docs in batch], [[d["score"] for d in docs] for docs in single], rtol=0, atol=2e-3)
+    assert r.last_error is None
+    store.close()
     emb.close()
 
 
