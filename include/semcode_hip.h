@@ -286,7 +286,8 @@ sc_status sc_index_last_search_stats(sc_index* ix, int32_t* path, int32_t* uncer
  * candidates), and only what fails there too to the exact scan -- results are identical whichever stage answers.  8 / 16 pin the
  * first stage (8: no bf16 stage in between).  An index whose int8 stage could not certify most of a batch starts at the bf16
  * stage from then on (tightly clustered corpora); setting 0 again clears that.  Under 0 the int8 stage is only taken from 2^20
- * rows up (below that its four times larger re-rank costs more than the coarse pass saves) or under search mode 2. */
+ * rows and 129 queries up (below that its four times larger re-rank, and its 256-query tiles, cost more than the coarse pass
+ * saves) or under search mode 2. */
 sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits);
 /* After a batched search: the stage it started on (8 / 16) and how many queries the int8 stage handed to the bf16 stage
  * (sc_index_last_search_stats' `uncertified` counts the queries that ended in the exact scan). */

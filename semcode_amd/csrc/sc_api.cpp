@@ -744,7 +744,9 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     // above all the IVF quantizer, whose nearest-centroid searches of a build went 6.4 -> 16.4 s through it at 4096 x 3072
     // (profiles/r2i_kernel_stats.csv: scan_rerank_kernel 7.4 s) -- start at the bf16 stage.
     // (search mode 2, "batched whenever supported", is the tests' switch: it keeps the int8 stage eligible at any size.)
-    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && (ix->n >= ((int64_t)1 << 20) || ix->search_mode == 2));
+    // ... and from 129 queries up: the int8 stage always runs 256-query tiles, and a batch of 32 spends 4.05 ms in them against the
+    // 3.8 ms of the bf16 stage's 128-query tiles (profiles/r2p_bench.json.log sweep vs r1v)
+    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= ((int64_t)1 << 20) && Q > 128) || ix->search_mode == 2));
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
     ix->last_uncertified = 0;
