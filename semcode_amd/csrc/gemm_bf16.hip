@@ -23,6 +23,10 @@
 
 #include "gemm_tile.h"
 
+#ifndef SC_GEMM_PP_DEFAULT
+#define SC_GEMM_PP_DEFAULT 0
+#endif
+
 // EPI_LNA_*: the A operand is a PRE-LayerNorm tensor y (raw bf16 rows) and the weights carry the LayerNorm's gamma
 // (W' = W diag(gamma)): with the row statistics mu, rs of y,  LN(y) W^T + b = rs (y W'^T - mu c1) + c2,  c1[n] = sum_k W'[n,k],
 // c2[n] = b[n] + sum_k beta[k] W[n,k] -- the normalisation becomes two FMAs in the epilogue and the LayerNorm kernel disappears.
@@ -426,7 +430,15 @@ static __device__ __forceinline__ void gemm256_stamp(const GemmArgs& a, int tile
     if (a.trace && threadIdx.x == 0) a.trace[(size_t)tile * 8 + slot] = (unsigned long long)wall_clock64();
 }
 
-template <int EPI, int DBG = 0>
+// PP = 0: the one-barrier main loop; 2..5: the ping-pong main loop with that many half-tiles in flight (gemm_tile.h)
+template <int PP, int ML, class Hook>
+static __device__ __forceinline__ void gemm256_mainloop_sel(const GemmArgs& a, int lda, int m0, int n0, char* smem, f32x4 (&acc)[4][8], int w, int lane, Hook hook,
+                                                            size_t a_kstep) {
+    if constexpr (PP > 0) gemm_tile256_mainloop_pp<PP, ML, Hook>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane, hook, a_kstep);
+    else gemm_tile256_mainloop<ML, Hook>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane, hook, a_kstep);
+}
+
+template <int EPI, int DBG = 0, int PP = 0>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 128 KiB pipeline buffers + epilogue staging
     const int lane = threadIdx.x & 63;
@@ -448,17 +460,16 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
     const int lda = a.ablock ? 64 : a.lda;
     const size_t a_kstep = a.ablock ? (size_t)a.M * 64 : (size_t)G_BK;
     if (EPI == EPI_BIAS_RES && !(DBG & 31))
-        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
-                                  ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
+        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane, ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
     else if (EPI == EPI_RESLN_STATS)
-        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
-                                  ResLnTailHook{ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
-                                                a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
+        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
+                                     ResLnTailHook{ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
+                                                   a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
     else if (EPI == EPI_LNA_BIAS || EPI == EPI_LNA_GELU)
-        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane,
-                                  LnaTailHook{a.stats_in + (size_t)(m0 + (w >> 2) * 128) * 2, (size_t)a.M * 2, a.stat_slots, w, lane, smem}, a_kstep);
+        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
+                                     LnaTailHook{a.stats_in + (size_t)(m0 + (w >> 2) * 128) * 2, (size_t)a.M * 2, a.stat_slots, w, lane, smem}, a_kstep);
     else
-        gemm_tile256_mainloop<ML>(a.A, lda, m0, a.W, a.ldw, n0, a.K, smem, acc, w, lane, NoTailHook{}, a_kstep);
+        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane, NoTailHook{}, a_kstep);
     gemm256_stamp(a, blockIdx.x, 3);
     if (DBG & 4) {  // diagnostic: no epilogue, keep the accumulators alive
         float sink = 0.f;
@@ -589,14 +600,31 @@ int sc_gemm_splitk_factor(int M, int N, int K, int cus) {
     return tiles * 2 <= cus ? best : 1;
 }
 
-template <int EPI, int DBG>
-static void launch256(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+// main loop of the 256-tile kernels: 0 = one barrier per K-tile, 2..5 = ping-pong with that many half-tiles in flight (SC_GEMM_PP)
+static int g_gemm_pp = -1;
+void sc_gemm_set_pp(int v) { g_gemm_pp = v; }
+static int gemm_pp() {
+    static const char* env = getenv("SC_GEMM_PP");
+    return g_gemm_pp >= 0 ? g_gemm_pp : env ? atoi(env) : SC_GEMM_PP_DEFAULT;
+}
+template <int EPI, int DBG, int PP>
+static void launch256_pp(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
     static bool attr = false;  // one per instantiation
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI, DBG, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, DBG>), grid, block, T_LDS_BYTES, s, a);  // 128 KiB pipeline + 18 KiB epilogue staging
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, DBG, PP>), grid, block, T_LDS_BYTES, s, a);  // 128 KiB pipeline + 18 KiB epilogue staging
+}
+template <int EPI, int DBG>
+static void launch256(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    const int pp = a.K >= 2 * G_BK ? gemm_pp() : 0;
+    if (pp == 0) return launch256_pp<EPI, DBG, 0>(a, grid, block, s);
+    if constexpr (DBG == 4) {  // other depths: only as the no-epilogue diagnostic
+        if (pp == 3) return launch256_pp<EPI, DBG, 3>(a, grid, block, s);
+        if (pp == 5) return launch256_pp<EPI, DBG, 5>(a, grid, block, s);
+    }
+    launch256_pp<EPI, DBG, 4>(a, grid, block, s);
 }
 template <int DBG>
 static void launch256_epi(int epi, const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {

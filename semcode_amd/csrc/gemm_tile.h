@@ -311,3 +311,176 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
     if (kt + 1 < nk) { ktile(kt, F{}, T{}); ++kt; }
     ktile(kt, F{}, F{});
 }
+
+// =====================================================================================================
+// Ping-pong form of the same 256 x 256 x 64 tile (round 3).  Same LDS budget, same accumulator layout, same order of
+// accumulation per output (bit-identical results), different schedule:
+//
+//   * the two waves of a SIMD (w and w + 4: wm = 0 / 1) run ONE barrier apart: while one multiplies a quadrant of its
+//     128 x 64 outputs (16 MFMAs) the other reads fragments and requests LDS-DMA pieces, then they swap.  In the
+//     one-barrier loop above both waves of a SIMD are in the same place at the same time: both burst their LDS-DMA
+//     requests (each blocks its wave's issue for 60-180 cycles) and both wait at the barrier, and the matrix pipe idles
+//     (profiles/r2n_gemm_k32_ab.log: the fill adds 145 us to 655 at 8k^3 although it would fit under the MFMAs).
+//   * a K-tile travels as FOUR half-tiles of 16 KiB, in the order they are read:
+//         j = 0: W0 = the W rows of every wave's ni 0..1     (rows wn * 64 + [ 0, 32))
+//         j = 1: A0 = the A rows of every wave's mi 0..3     (rows wm * 128 + [ 0, 64))
+//         j = 2: A1 = ... mi 4..7                            (rows wm * 128 + [64, 128))
+//         j = 3: W1 = ... ni 2..3                            (rows wn * 64 + [32, 64))
+//     through a ring of 8 slots (the same 128 KiB).  Half-tile h = 4 t + j is read in phase h - 1 and requested in phase
+//     h - D - 2: D half-tiles (2 D pieces per wave) are always in flight, waited for with a counted vmcnt once per phase.
+//   * phases of K-tile t (P = 4 t + p), each {LOAD segment | barrier | MFMA segment | barrier}:
+//         p  reads (ds_read_b128)      multiplies                    requests
+//         0  A0(t)      8              Q(0,0) = A0 x W0              half-tile P + D + 2
+//         1  A1(t)      8              Q(1,0) = A1 x W0                ''
+//         2  W1(t)      4              Q(1,1) = A1 x W1                ''
+//         3  W0(t + 1)  4              Q(0,1) = A0 x W1                ''
+//     every fragment register is loaded in a LOAD segment in which its previous contents are dead: 96 fragment VGPRs, no
+//     double buffering.
+//   * hazards.  RAW: half-tile h was requested by all waves in phase h - D - 2; every wave waits for its own pieces
+//     (vmcnt(2 D) after requesting in phase h - 2) before the barrier that ends that LOAD segment, wave group 1 one barrier
+//     later than group 0, and the first read is in phase h - 1, behind both.  WAR: slot (h mod 8) is rewritten in phase
+//     h + 6 - D at the earliest (D <= 5: two segments after wave group 1 read it, whose reads have returned before its
+//     MFMA segment starts).
+// K >= 128 (two K-tiles); the launchers fall back to the one-barrier loop otherwise.
+// =====================================================================================================
+template <bool I8>
+static __device__ __forceinline__ f32x4 pp_mma(const bf16x8& wv, const bf16x8& av, const f32x4& c) {
+    if (I8)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, wv), __builtin_bit_cast(i32x4_t, av),
+                                                                              __builtin_bit_cast(i32x4_t, c), 0, 0, 0));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, c, 0, 0, 0);
+}
+
+#define SC_PP_BARRIER_VM(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
+#define SC_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int D, int DBG = 0, class TailHook = NoTailHook, bool I8 = false>
+static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
+                                                                 int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
+                                                                 TailHook tail = TailHook{}, size_t a_kstep = G_BK) {
+    static_assert(D >= 2 && D <= 5, "half-tiles in flight");
+    constexpr bool HOOK = !std::is_same<TailHook, NoTailHook>::value;
+    const int wm = w >> 2, wn = w & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = K / G_BK;
+    // sources: buffer descriptors (base + 32-bit per-lane offset + scalar K offset: no 64-bit vector arithmetic per piece)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
+    const uint32_t a_kbytes = (uint32_t)(a_kstep * 2), a1_off = (uint32_t)(64 * lda * 2), w1_off = (uint32_t)(32 * ldw * 2);
+    uint32_t va[2], vw[2];  // byte offsets of this lane's 16 bytes in the wave's two pieces (8 rows x 128 B each) of an A / W half-tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (2 * w + i) * 8 + (lane >> 3), pos = lane & 7;
+        const int c = pos ^ ((lr >> 1) & 7);  // LDS-DMA writes linearly: the swizzle is applied on the source address
+        va[i] = (uint32_t)(((lr >> 6) * 128 + (lr & 63)) * lda * 2 + c * 16);
+        vw[i] = (uint32_t)(((lr >> 5) * 64 + (lr & 31)) * ldw * 2 + c * 16);
+    }
+    // fragment rows of this lane inside an A / W half-tile image (k-step 0; k-step 1 = the same address ^ 64)
+    const uint32_t rd_sw = (uint32_t)(fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4));
+    const uint32_t a_rd = (uint32_t)(wm * 64 * 128) + rd_sw, w_rd = (uint32_t)(wn * 32 * 128) + rd_sw;
+
+    bf16x8 fa0[4][2], fa1[4][2], fw0[2][2], fw1[2][2];
+    auto stage = [&](int t, int j) {  // request this wave's two pieces of half-tile j of K-tile t
+        if (DBG & 1) return;
+        char* dst = smem + (((t & 1) * 4 + j) * 16384 + 2 * w * 1024);
+        if (j == 1 || j == 2) {
+            const uint32_t so = (uint32_t)t * a_kbytes + (j == 2 ? a1_off : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)dst, 16, va[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(dst + 1024), 16, va[1], so, 0, 0);
+        } else {
+            const uint32_t so = (uint32_t)t * (uint32_t)(G_BK * 2) + (j == 3 ? w1_off : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)dst, 16, vw[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(dst + 1024), 16, vw[1], so, 0, 0);
+        }
+    };
+    auto rdA = [&](bf16x8 (&dst)[4][2], int t, int j) {
+        if (DBG & 4) return;
+        const char* b = smem + (uint32_t)((t & 1) << 16);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[mi][ks] = *reinterpret_cast<const bf16x8*>(b + ((a_rd ^ (uint32_t)(ks << 6)) + j * 16384 + mi * 2048));
+    };
+    auto rdW = [&](bf16x8 (&dst)[2][2], int t, int j) {
+        if (DBG & 4) return;
+        const char* b = smem + (uint32_t)((t & 1) << 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[ni][ks] = *reinterpret_cast<const bf16x8*>(b + ((w_rd ^ (uint32_t)(ks << 6)) + j * 16384 + ni * 2048));
+    };
+    auto quad = [&](const bf16x8 (&fa)[4][2], const bf16x8 (&fw)[2][2], int mh, int nh) {
+        if (DBG & 2) {
+            asm volatile("" ::"v"(fa[0][0]), "v"(fa[3][1]), "v"(fw[0][0]), "v"(fw[1][1]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[nh * 2 + ni][mh * 4 + mi] = pp_mma<I8>(fw[ni][ks], fa[mi][ks], acc[nh * 2 + ni][mh * 4 + mi]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: half-tiles 0 .. D + 1 requested, 0 and 1 (W0, A0 of K-tile 0) landed and visible, W0(0) in registers
+#pragma unroll
+    for (int h = 0; h <= D + 1; ++h) {
+        const bool keep = DBG & 1;  // (the ablation drops the in-loop requests only)
+        if (!keep) stage(h >> 2, h & 3);
+        else {
+            char* dst = smem + (((h >> 2) & 1) * 4 + (h & 3)) * 16384 + 2 * w * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)dst, 16, vw[0], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(dst + 1024), 16, vw[1], 0, 0, 0);
+        }
+    }
+    SC_PP_BARRIER_VM(2 * D);
+    rdW(fw0, 0, 0);
+    if (wm) SC_PP_BARRIER();  // wave group 1 runs one barrier behind group 0 from here on
+    __builtin_amdgcn_sched_barrier(0);
+
+    // MODE 0: K-tiles 0 .. nk - 3 (every request exists); 1: K-tile nk - 2; 2: K-tile nk - 1
+    auto ktile = [&](int t, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        auto phase = [&](auto p_c) {
+            constexpr int p = decltype(p_c)::value;
+            constexpr int hs = p + D + 2;  // the half-tile requested in this phase, relative to 4 t
+            constexpr bool ST = MODE == 0 || (MODE == 1 && hs < 8);
+            // half-tiles that may stay in flight behind this phase's wait (the one read in phase P + 1 must have landed)
+            constexpr int FL = MODE == 0 ? D : MODE == 1 ? (D < 5 - p ? D : 5 - p) : (p == 0 ? 1 : 0);
+            // ---- LOAD segment
+            if (p == 0) rdA(fa0, t, 1);
+            if (p == 1) rdA(fa1, t, 2);
+            if (p == 2) rdW(fw1, t, 3);
+            if (p == 3 && MODE != 2) rdW(fw0, t + 1, 0);
+            if (ST) stage(t + (hs >> 2), hs & 3);
+            if (MODE == 2 && p == 3) tail();
+            if (MODE == 2 && p == 2 && HOOK) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the hook rewrites slots other waves read
+            if (MODE == 2 && p >= 2) SC_PP_BARRIER();
+            else SC_PP_BARRIER_VM(2 * FL);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA segment
+            if (p == 0) quad(fa0, fw0, 0, 0);
+            if (p == 1) quad(fa1, fw0, 1, 0);
+            if (p == 2) quad(fa1, fw1, 1, 1);
+            if (p == 3) quad(fa0, fw1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 2 && p == 3) {
+                if (!wm) SC_PP_BARRIER();  // group 1 is one barrier behind: this is group 0's last
+            } else {
+                SC_PP_BARRIER();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 0>{});
+    ktile(t, std::integral_constant<int, 1>{});
+    ktile(t + 1, std::integral_constant<int, 2>{});
+}

@@ -47,6 +47,7 @@ void sc_launch_bf16_to_f32(const void* in, float* out, int64_t n, hipStream_t s)
 
 void sc_gemm_set_debug(int v);
 void sc_gemm_set_order(int v);
+void sc_gemm_set_pp(int v);
 void sc_gemm_set_trace(unsigned long long* dev);
 void sc_gemm_force_tile128(bool on);
 
@@ -759,6 +760,10 @@ extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, 
     sc_launch_f32_to_bf16((const float*)fw.p, dw.p, nw, s);
     SC_HIP(hipMemsetAsync(db.p, 0, (size_t)N * 4, s));
     SC_HIP(hipMemsetAsync(dr.p, 0, (size_t)nc * 2, s));
+    // variant = 100000 * pp + v: pp = main loop of the 256-tile kernel (0 = as configured, 1 = one barrier per K-tile, 2..5 = ping-pong depth)
+    const int pp = variant / 100000;
+    variant %= 100000;
+    sc_gemm_set_pp(pp == 0 ? -1 : pp == 1 ? 0 : pp);
     sc_gemm_force_tile128(variant == 128);
     sc_gemm_set_debug((variant == 128 || variant >= 1000) ? 0 : variant);
     sc_gemm_set_order(variant >= 1000 ? variant - 1000 : 16);  // variants 1000+o: tile order o with the real epilogue
@@ -773,6 +778,7 @@ extern "C" sc_status sc_diag_gemm_bench(sc_runtime* rt, int32_t epi, int32_t M, 
     sc_gemm_force_tile128(false);
     sc_gemm_set_debug(0);
     sc_gemm_set_order(16);
+    sc_gemm_set_pp(-1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0);
