@@ -24,7 +24,7 @@
 #include "gemm_tile.h"
 
 #ifndef SC_GEMM_PP_DEFAULT
-#define SC_GEMM_PP_DEFAULT 0
+#define SC_GEMM_PP_DEFAULT 4
 #endif
 
 // EPI_LNA_*: the A operand is a PRE-LayerNorm tensor y (raw bf16 rows) and the weights carry the LayerNorm's gamma
@@ -139,9 +139,12 @@ static __device__ __forceinline__ void tile_coords256(const GemmArgs& a, int vt,
 // residual cost a full load + store round trip per block: 12 us per tile against a 20 us main loop
 // (profiles/r1o_gemm_trace.log).
 struct ResidualTailHook {
+    static constexpr bool kCoop = false;
     const bf16_t* R;  // tile origin: R + m0 * ldr + n0
     int ldr, w, lane;
     char* smem;
+    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         int ln = lane;
         asm volatile("" : "+v"(ln));  // keep the address arithmetic out of the register-tight K loop
@@ -161,10 +164,13 @@ struct ResidualTailHook {
 // EPI_LNA_*: the partial row sums of this wave's 128 rows, stat_slots pieces of 1 KiB (128 rows x {sum, sumsq} f32), into the wave's
 // own slice of the dead pipeline buffers, under the last 32 MFMAs.
 struct LnaTailHook {
+    static constexpr bool kCoop = false;
     const float* stats;  // stats_in + (m0 + wm * 128) * 2, slot stride = M * 2 floats
     size_t slot_stride;
     int slots, w, lane;
     char* smem;
+    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -176,10 +182,56 @@ struct LnaTailHook {
 // EPI_RESLN_STATS: the residual tile as in ResidualTailHook, plus the finalised (mu, rs) of this wave's 128 rows (1 KiB) into its
 // epilogue staging slice (read into registers before the first staging write).
 struct ResLnTailHook {
+    static constexpr bool kCoop = false;
     ResidualTailHook res;
     const float* fin;  // fin + (m0 + wm * 128) * 2
+    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         res();
+        int ln = res.lane;
+        asm volatile("" : "+v"(ln));
+        __builtin_amdgcn_global_load_lds((gbl_vptr)(fin + ln * 4), (lds_vptr)(res.smem + 4 * T_TILE_BYTES + res.w * (16 * T_EPI_ROW)), 16, 0, 0);
+    }
+};
+
+// Ping-pong main loop: the residual tile continues the ring (gemm_tile.h, "tail hooks").  Slot s receives the 128 x 64 part of
+// wave s -- the image the epilogues read from smem + w * 16384, same swizzle -- but every wave requests two of its 16 pieces
+// (pieces 2 w, 2 w + 1: rows 16 w .. 16 w + 15 of the part), one slot per phase as the slots fall free: the requests are spread
+// over the last 1.5 K-tiles like the loop's own instead of bursting 16 per wave into the last phase (out-projection:
+// gpurun_out/r3b_gemm_pp_epi.log, 88 us per launch of which ~6 per tile were this epilogue's fetch).  The epilogue then needs
+// vmcnt(0) + one barrier of all 8 waves before its first read.
+struct ResidualCoopHook {
+    static constexpr bool kCoop = true;
+    const bf16_t* R;  // tile origin: R + m0 * ldr + n0
+    int ldr, w, lane;
+    char* smem;
+    __amdgpu_buffer_rsrc_t rr;
+    uint32_t v0, v1;
+    __device__ __forceinline__ void prepare() {  // called once, in front of the last two K-tiles
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // keep the address arithmetic out of the register-tight K loop
+        rr = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, -1, 0x00020000);
+        const int prow = ln >> 3, pos = ln & 7;
+        const int r0 = 16 * w + prow, r1 = r0 + 8;
+        v0 = (uint32_t)((r0 * ldr + (pos ^ ((r0 >> 1) & 7)) * 8) * 2);
+        v1 = (uint32_t)((r1 * ldr + (pos ^ ((r1 >> 1) & 7)) * 8) * 2);
+    }
+    __device__ __forceinline__ void coop(int slot) const {
+        const uint32_t so = (uint32_t)(((slot >> 2) * 128 * ldr + (slot & 3) * 64) * 2);
+        char* dst = smem + slot * 16384 + 2 * w * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_vptr)dst, 16, v0, so, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_vptr)(dst + 1024), 16, v1, so, 0, 2);
+    }
+    __device__ __forceinline__ void operator()() const {}
+};
+struct ResLnCoopHook {
+    static constexpr bool kCoop = true;
+    ResidualCoopHook res;
+    const float* fin;  // fin + (m0 + wm * 128) * 2
+    __device__ __forceinline__ void prepare() { res.prepare(); }
+    __device__ __forceinline__ void coop(int slot) const { res.coop(slot); }
+    __device__ __forceinline__ void operator()() const {  // the wave's own (mu, rs) rows into its own staging slice
         int ln = res.lane;
         asm volatile("" : "+v"(ln));
         __builtin_amdgcn_global_load_lds((gbl_vptr)(fin + ln * 4), (lds_vptr)(res.smem + 4 * T_TILE_BYTES + res.w * (16 * T_EPI_ROW)), 16, 0, 0);
@@ -201,7 +253,7 @@ struct ResLnTailHook {
 // in f32 before the single bf16 rounding.  DS operations of one wave execute in order, so the slice is reused without
 // waits beyond the data dependencies.  Everything per lane is derived from an opaque copy of the lane id so that hipcc
 // cannot hoist it above the register-tight K loop.
-template <int EPI>
+template <int EPI, bool COOP = false>
 static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m0, int n0, char* smem, int w, int lane, f32x4 (&acc)[4][8]) {
     const int wm = w >> 2, wn = w & 3;
     int ln = lane;
@@ -220,7 +272,8 @@ static __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& a, int m
     u32x2 rr[8][4];  // residual in the MFMA layout, read up front (the fragment registers are dead): the compiler cannot
                      // move LDS reads across the staging writes below, and one read -> add -> write chain per block is slow
     if (EPI == EPI_BIAS_RES) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's residual DMA has landed
+        if (COOP) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of every part have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's residual DMA has landed
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -334,6 +387,7 @@ static __device__ __forceinline__ void gemm256_epilogue_lna(const GemmArgs& a, i
 
 // EPI_RESLN_STATS: out = acc + bias[n] + (r - mu_m) rs_m gam[n]   (r = the raw pre-LayerNorm residual, bias already holds + beta),
 // and the partial sums (sum, sum of squares) of this tile's 256 columns of the bf16-ROUNDED output, per row, into stats_out.
+template <bool COOP = false>
 static __device__ __forceinline__ void gemm256_epilogue_resln(const GemmArgs& a, int m0, int n0, char* smem, int w, int lane, f32x4 (&acc)[4][8]) {
     const int wm = w >> 2, wn = w & 3;
     int ln = lane;
@@ -351,7 +405,8 @@ static __device__ __forceinline__ void gemm256_epilogue_resln(const GemmArgs& a,
         bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + ni * 16 + 4 * fq);
         gam4[ni] = *reinterpret_cast<const f32x4*>(a.gam + n0 + wn * 64 + ni * 16 + 4 * fq);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // residual tile + row statistics have landed
+    if (COOP) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of the residual tile + this wave's row statistics
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // residual tile + row statistics have landed
     f32x2_t st[8];  // (mu, rs) of this lane's 8 rows: out of the staging slice before it is written
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) st[mi] = *reinterpret_cast<const f32x2_t*>(stg + (mi * 16 + fr) * 8);
@@ -459,12 +514,22 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
     constexpr int ML = (DBG & 3) | ((DBG & 16) ? 4 : 0);
     const int lda = a.ablock ? 64 : a.lda;
     const size_t a_kstep = a.ablock ? (size_t)a.M * 64 : (size_t)G_BK;
-    if (EPI == EPI_BIAS_RES && !(DBG & 31))
-        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane, ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
-    else if (EPI == EPI_RESLN_STATS)
-        gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
-                                     ResLnTailHook{ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
-                                                   a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
+    constexpr bool COOP = PP > 0;  // ping-pong loop: the residual tile comes through the ring
+    if (EPI == EPI_BIAS_RES && !(DBG & 31)) {
+        if constexpr (COOP)
+            gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane, ResidualCoopHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
+        else
+            gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane, ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem}, a_kstep);
+    } else if (EPI == EPI_RESLN_STATS) {
+        if constexpr (COOP)
+            gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
+                                         ResLnCoopHook{ResidualCoopHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
+                                                       a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
+        else
+            gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
+                                         ResLnTailHook{ResidualTailHook{a.R + (size_t)m0 * a.ldr + n0, a.ldr, w, lane, smem},
+                                                       a.fin + (size_t)(m0 + (w >> 2) * 128) * 2}, a_kstep);
+    }
     else if (EPI == EPI_LNA_BIAS || EPI == EPI_LNA_GELU)
         gemm256_mainloop_sel<PP, ML>(a, lda, m0, n0, smem, acc, w, lane,
                                      LnaTailHook{a.stats_in + (size_t)(m0 + (w >> 2) * 128) * 2, (size_t)a.M * 2, a.stat_slots, w, lane, smem}, a_kstep);
@@ -480,9 +545,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(GemmArgs a) {
         if (sink == 12345.678f) a.C[0] = 1;
         return;
     }
-    if (EPI == EPI_RESLN_STATS) gemm256_epilogue_resln(a, m0, n0, smem, w, lane, acc);
+    if (EPI == EPI_RESLN_STATS) gemm256_epilogue_resln<COOP>(a, m0, n0, smem, w, lane, acc);
     else if (EPI == EPI_LNA_BIAS || EPI == EPI_LNA_GELU) gemm256_epilogue_lna<EPI>(a, m0, n0, smem, w, lane, acc);
-    else gemm256_epilogue<EPI>(a, m0, n0, smem, w, lane, acc);
+    else gemm256_epilogue<EPI, COOP && !(DBG & 31)>(a, m0, n0, smem, w, lane, acc);
     if (a.trace) {
         gemm256_stamp(a, blockIdx.x, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

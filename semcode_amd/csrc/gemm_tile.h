@@ -234,7 +234,10 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 // reads the 128 KiB of pipeline buffers again, so the hook may start LDS-DMA into them for the epilogue (the residual
 // tile, gemm_bf16.hip) and have it land under those MFMAs.
 struct NoTailHook {
+    static constexpr bool kCoop = false;
     __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void prepare() {}
 };
 // request K-tiles 0 and 1 of a tile (16 LDS-DMA pieces per wave)
 static __device__ __forceinline__ void gemm_tile256_prologue_issue(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W,
@@ -341,6 +344,14 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
 //     later than group 0, and the first read is in phase h - 1, behind both.  WAR: slot (h mod 8) is rewritten in phase
 //     h + 6 - D at the earliest (D <= 5: two segments after wave group 1 read it, whose reads have returned before its
 //     MFMA segment starts).
+//   * tail hooks.  tail() runs in the LOAD segment of the very last phase, when no wave reads the ring any more (wave-private
+//     LDS-DMA into the wave's own 16 KiB, as in the one-barrier loop).  A hook with kCoop instead continues the ring: once the
+//     K-tiles' own requests have ended, slot after slot falls free (one per phase, in the order they were read) and
+//     coop(slot) -- called by EVERY wave in each of the last 7 phases and once behind the loop -- requests that wave's two
+//     pieces of whatever the epilogue wants in that slot (gemm_bf16.hip: the residual tile, slot s = the 128 x 64 part of wave
+//     s).  Same 2 pieces per wave and phase as the loop's own requests, in flight while the last 1.5 K-tiles multiply; the
+//     caller waits vmcnt(0) and passes ONE more barrier (all 8 waves) before reading, because every wave's pieces are in
+//     every slot.  The counted waits include the hook's pieces (vmcnt counts in issue order).
 // K >= 128 (two K-tiles); the launchers fall back to the one-barrier loop otherwise.
 // =====================================================================================================
 template <bool I8>
@@ -360,9 +371,11 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
                                                                  TailHook tail = TailHook{}, size_t a_kstep = G_BK) {
     static_assert(D >= 2 && D <= 5, "half-tiles in flight");
     constexpr bool HOOK = !std::is_same<TailHook, NoTailHook>::value;
+    constexpr bool COOP = TailHook::kCoop;
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
+    const int coop0 = (nk & 1) * 4 + 7;  // slot read in phase Q - 2 of the last two K-tiles: (coop0 + Q) & 7
     // sources: buffer descriptors (base + 32-bit per-lane offset + scalar K offset: no 64-bit vector arithmetic per piece)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
@@ -447,17 +460,25 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
             constexpr int p = decltype(p_c)::value;
             constexpr int hs = p + D + 2;  // the half-tile requested in this phase, relative to 4 t
             constexpr bool ST = MODE == 0 || (MODE == 1 && hs < 8);
-            // half-tiles that may stay in flight behind this phase's wait (the one read in phase P + 1 must have landed)
-            constexpr int FL = MODE == 0 ? D : MODE == 1 ? (D < 5 - p ? D : 5 - p) : (p == 0 ? 1 : 0);
+            // Q: phase number within the last two K-tiles.  Pairs of pieces that may stay in flight behind this phase's wait (the
+            // half-tile read in phase Q + 1 was requested in phase Q - D and must have landed; everything younger may fly): the
+            // K-tiles' own requests of phases Q - D + 1 .. Q (they end with phase 5 - D) and, with a cooperative hook, its
+            // requests of phases max(1, Q - D) .. min(Q, 7).
+            constexpr int Q = MODE == 0 ? -8 : MODE == 1 ? p : 4 + p;
+            constexpr int NST = MODE == 0 ? D : ((Q < 5 - D ? Q : 5 - D) - Q + D > 0 ? (Q < 5 - D ? Q : 5 - D) - Q + D : 0);
+            constexpr int RLO = Q - D > 1 ? Q - D : 1, RHI = Q < 7 ? Q : 7;
+            constexpr int NRES = (COOP && MODE != 0 && RHI >= RLO) ? RHI - RLO + 1 : 0;
+            constexpr int FL = NST + NRES;
             // ---- LOAD segment
             if (p == 0) rdA(fa0, t, 1);
             if (p == 1) rdA(fa1, t, 2);
             if (p == 2) rdW(fw1, t, 3);
             if (p == 3 && MODE != 2) rdW(fw0, t + 1, 0);
             if (ST) stage(t + (hs >> 2), hs & 3);
+            if (COOP && Q >= 1) tail.coop((coop0 + Q) & 7);
             if (MODE == 2 && p == 3) tail();
             if (MODE == 2 && p == 2 && HOOK) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the hook rewrites slots other waves read
-            if (MODE == 2 && p >= 2) SC_PP_BARRIER();
+            if (MODE == 2 && p >= 2) SC_PP_BARRIER();  // (nothing of the K-tiles is in flight any more)
             else SC_PP_BARRIER_VM(2 * FL);
             __builtin_amdgcn_sched_barrier(0);
             // ---- MFMA segment
@@ -481,6 +502,8 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
     int t = 0;
 #pragma unroll 1
     for (; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 0>{});
+    tail.prepare();
     ktile(t, std::integral_constant<int, 1>{});
     ktile(t + 1, std::integral_constant<int, 2>{});
+    if (COOP) tail.coop((coop0 + 8) & 7);  // the slot of the last half-tile read
 }
