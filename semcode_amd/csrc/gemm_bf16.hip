@@ -482,7 +482,11 @@ static __device__ __forceinline__ void gemm256_epilogue_resln(const GemmArgs& a,
 
 // diagnostic time stamps (100 MHz wall clock): slot 0 = HW_ID, 1 = XCC_ID, 2.. = stamps
 static __device__ __forceinline__ void gemm256_stamp(const GemmArgs& a, int tile, int slot) {
-    if (a.trace && threadIdx.x == 0) a.trace[(size_t)tile * 8 + slot] = (unsigned long long)wall_clock64();
+    if (a.trace && threadIdx.x == 0) {
+        a.trace[(size_t)tile * 8 + slot] = (unsigned long long)wall_clock64();
+        // slots 6 / 7: the shader clock (s_memtime) next to stamps 2 / 3 -- cycles of the main loop, and with the 100 MHz stamps the clock it ran at
+        if (slot == 2 || slot == 3) a.trace[(size_t)tile * 8 + slot + 4] = (unsigned long long)__builtin_readcyclecounter();
+    }
 }
 
 // PP = 0: the one-barrier main loop; 2..5: the ping-pong main loop with that many half-tiles in flight (gemm_tile.h)
@@ -771,6 +775,7 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
             case 2: launch256<EPI_BIAS, 2>(a, grid, block, s); return;
             case 4: launch256<EPI_BIAS, 4>(a, grid, block, s); return;
             case 5: launch256<EPI_BIAS, 5>(a, grid, block, s); return;
+            case 20: launch256<EPI_BIAS, 20>(a, grid, block, s); return;
             case 21: launch256<EPI_BIAS, 21>(a, grid, block, s); return;
             default: break;
         }

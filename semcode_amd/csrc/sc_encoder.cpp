@@ -731,12 +731,14 @@ extern "C" sc_status sc_diag_gemm_trace(sc_runtime* rt, int32_t epi, int32_t M, 
     SC_HIP(hipMemsetAsync(db.p, 0, (size_t)N * 4, s));
     SC_HIP(hipMemsetAsync(dr.p, 0, (size_t)nc * 2, s));
     SC_HIP(hipMemsetAsync(tr.p, 0, trace_bytes, s));
+    if (const char* e = getenv("SC_GEMM_TRACE_DBG")) sc_gemm_set_debug(atoi(e));  // stamps around an ablated main loop (scripts/gemm_clock.py)
     for (int i = 0; i < 2; ++i) sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
     for (int64_t l = 0; l < launches; ++l) {
         sc_gemm_set_trace((unsigned long long*)tr.p + l * ntiles * 8);
         sc_launch_gemm_bf16(epi, da.p, K, dw.p, K, (const float*)db.p, dr.p, N, dc.p, N, M, N, K, s);
     }
     sc_gemm_set_trace(nullptr);
+    sc_gemm_set_debug(0);
     hipError_t he = hipStreamSynchronize(s);
     if (he != hipSuccess) return sc_fail(SC_ERR_HIP, "diag gemm trace failed: %s", hipGetErrorString(he));
     SC_HIP(hipMemcpy(out, tr.p, trace_bytes, hipMemcpyDeviceToHost));

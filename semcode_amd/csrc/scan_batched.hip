@@ -426,7 +426,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
 
-template <int METRIC, int DBG = 0, bool I8 = false>
+// PP: 0 = one barrier per K-tile, 2..5 = the ping-pong main loop with that many half-tiles in flight (gemm_tile.h)
+template <int METRIC, int DBG = 0, bool I8 = false, int PP = 4>
 __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // int8 stage: a.ld counts PAIRS of int8 (the tile machinery addresses 2-byte elements), zero accumulators are zero i32 bits
-    gemm_tile256_mainloop<0, NoTailHook, I8>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+    if constexpr (PP > 0) gemm_tile256_mainloop_pp<PP, 0, NoTailHook, I8>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
+    else gemm_tile256_mainloop<0, NoTailHook, I8>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane);
     asm volatile("" ::: "memory");  // keep the epilogue's loads out of the register-tight main loop
     __builtin_amdgcn_sched_barrier(0);
     if ((DBG & 2) && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)wall_clock64();
@@ -824,12 +826,16 @@ int sc_batched_kprime8(void) { return KPRIME8; }
 
 template <int METRIC, bool I8>
 static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
+    static const char* env = getenv("SC_COARSE_PP");  // A/B: 0 = the one-barrier main loop
+    static const bool pp = (env ? atoi(env) : 4) != 0;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    if (pp && a.ld >= 2 * G_BK) hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 4>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 0>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
 }
 
 // i8: Xb / Qb are the int8 shadows with rows of ld8 bytes (`ld` is then ld8), xscale / qscale their per-row scales; the batch must be
