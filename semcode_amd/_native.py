@@ -75,6 +75,7 @@ SIGNATURES = {
     "sc_diag_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_gemm_bench": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sc_diag_gemm_trace": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "sc_diag_set_option": (C.c_int32, [C.c_char_p, C.c_int32]),
     "sc_diag_gemm_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sc_diag_encoder_read": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "sc_diag_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -599,6 +600,11 @@ def diag_gemm_bf16(rt: Runtime, A, W, bias, R=None, epi: int = 0) -> np.ndarray:
     _check(lib().sc_diag_gemm_bf16(rt.handle, epi, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
                                    bias.ctypes.data_as(C.c_void_p), Rp, M, N, K, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def diag_set_option(name: str, value: int) -> None:
+    """Process-wide test / tuning switch of the library (sc_diag_set_option)."""
+    _check(lib().sc_diag_set_option(name.encode(), int(value)))
 
 
 def diag_gemm_bench(rt: Runtime, M: int, N: int, K: int, epi: int = 0, iters: int = 20, variant: int = 0) -> float:

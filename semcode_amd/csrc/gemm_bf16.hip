@@ -143,7 +143,7 @@ struct ResidualTailHook {
     const bf16_t* R;  // tile origin: R + m0 * ldr + n0
     int ldr, w, lane;
     char* smem;
-    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void coop(int, int, const uint32_t (&)[2], const uint32_t (&)[2]) const {}
     __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         int ln = lane;
@@ -169,7 +169,7 @@ struct LnaTailHook {
     size_t slot_stride;
     int slots, w, lane;
     char* smem;
-    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void coop(int, int, const uint32_t (&)[2], const uint32_t (&)[2]) const {}
     __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         int ln = lane;
@@ -185,7 +185,7 @@ struct ResLnTailHook {
     static constexpr bool kCoop = false;
     ResidualTailHook res;
     const float* fin;  // fin + (m0 + wm * 128) * 2
-    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void coop(int, int, const uint32_t (&)[2], const uint32_t (&)[2]) const {}
     __device__ __forceinline__ void prepare() {}
     __device__ __forceinline__ void operator()() const {
         res();
@@ -217,7 +217,7 @@ struct ResidualCoopHook {
         v0 = (uint32_t)((r0 * ldr + (pos ^ ((r0 >> 1) & 7)) * 8) * 2);
         v1 = (uint32_t)((r1 * ldr + (pos ^ ((r1 >> 1) & 7)) * 8) * 2);
     }
-    __device__ __forceinline__ void coop(int slot) const {
+    __device__ __forceinline__ void coop(int slot, int, const uint32_t (&)[2], const uint32_t (&)[2]) const {
         const uint32_t so = (uint32_t)(((slot >> 2) * 128 * ldr + (slot & 3) * 64) * 2);
         char* dst = smem + slot * 16384 + 2 * w * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_vptr)dst, 16, v0, so, 0, 2);
@@ -230,7 +230,7 @@ struct ResLnCoopHook {
     ResidualCoopHook res;
     const float* fin;  // fin + (m0 + wm * 128) * 2
     __device__ __forceinline__ void prepare() { res.prepare(); }
-    __device__ __forceinline__ void coop(int slot) const { res.coop(slot); }
+    __device__ __forceinline__ void coop(int slot, int h, const uint32_t (&va)[2], const uint32_t (&vw)[2]) const { res.coop(slot, h, va, vw); }
     __device__ __forceinline__ void operator()() const {  // the wave's own (mu, rs) rows into its own staging slice
         int ln = res.lane;
         asm volatile("" : "+v"(ln));

@@ -236,7 +236,7 @@ static __device__ __forceinline__ void mfma_frags256(const Frag256& f, f32x4 (&a
 struct NoTailHook {
     static constexpr bool kCoop = false;
     __device__ __forceinline__ void operator()() const {}
-    __device__ __forceinline__ void coop(int) const {}
+    __device__ __forceinline__ void coop(int, int, const uint32_t (&)[2], const uint32_t (&)[2]) const {}
     __device__ __forceinline__ void prepare() {}
 };
 // request K-tiles 0 and 1 of a tile (16 LDS-DMA pieces per wave)
@@ -352,8 +352,48 @@ static __device__ __forceinline__ void gemm_tile256_mainloop(const bf16_t* __res
 //     s).  Same 2 pieces per wave and phase as the loop's own requests, in flight while the last 1.5 K-tiles multiply; the
 //     caller waits vmcnt(0) and passes ONE more barrier (all 8 waves) before reading, because every wave's pieces are in
 //     every slot.  The counted waits include the hook's pieces (vmcnt counts in issue order).
+//   * persistent use (PREF, scan_batched.hip).  A workgroup that walks several output tiles hands PPNextTileHook to the loop: its
+//     coop() requests half-tiles 0 .. 7 (the first TWO K-tiles) of the NEXT output tile into the falling-free slots, in ring order
+//     (they are the slots the next tile's loop expects when it starts with buffer parity par ^ (nk & 1)).  The next call (PREF)
+//     then has no prologue requests: it waits for half-tiles 0 and 1 (vmcnt(12): six younger half-tiles; anything the caller's
+//     epilogue issued in between is younger still and only makes the wait conservative), and its K-tile 0 requests nothing before
+//     half-tile 8.  The memory latency of a tile's first bytes and two K-tiles of fill then hide under the previous tile's tail and
+//     epilogue instead of opening every tile (coarse scan, 6 K-tiles per tile: profiles/r3g_coarse_trace.log).  K >= 192 there.
 // K >= 128 (two K-tiles); the launchers fall back to the one-barrier loop otherwise.
 // =====================================================================================================
+// requests half-tile h (0 .. 7) of an output tile into `slot`: the cooperative hook of a persistent caller (see above)
+struct PPNextTileHook {
+    static constexpr bool kCoop = true;
+    __amdgpu_buffer_rsrc_t ra, rw;  // the next tile's A rows / W rows
+    uint32_t a_kbytes, a1_off, w1_off;
+    int w;
+    char* smem;
+    __device__ __forceinline__ void coop(int slot, int h, const uint32_t (&va)[2], const uint32_t (&vw)[2]) const {
+        const int t = h >> 2, j = h & 3;
+        char* dst = smem + (slot * 16384 + 2 * w * 1024);
+        if (j == 1 || j == 2) {
+            const uint32_t so = (uint32_t)t * a_kbytes + (j == 2 ? a1_off : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)dst, 16, va[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(dst + 1024), 16, va[1], so, 0, 0);
+        } else {
+            const uint32_t so = (uint32_t)t * (uint32_t)(G_BK * 2) + (j == 3 ? w1_off : 0u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)dst, 16, vw[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(dst + 1024), 16, vw[1], so, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void prepare() {}
+};
+// per-lane source offsets of a wave's two pieces of an A / W half-tile (shared by the loop and by a persistent caller's first prefetch)
+static __device__ __forceinline__ void pp_piece_offsets(int lda, int ldw, int w, int lane, uint32_t (&va)[2], uint32_t (&vw)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (2 * w + i) * 8 + (lane >> 3), pos = lane & 7;
+        const int c = pos ^ ((lr >> 1) & 7);  // LDS-DMA writes linearly: the swizzle is applied on the source address
+        va[i] = (uint32_t)(((lr >> 6) * 128 + (lr & 63)) * lda * 2 + c * 16);
+        vw[i] = (uint32_t)(((lr >> 5) * 64 + (lr & 31)) * ldw * 2 + c * 16);
+    }
+}
 template <bool I8>
 static __device__ __forceinline__ f32x4 pp_mma(const bf16x8& wv, const bf16x8& av, const f32x4& c) {
     if (I8)
@@ -365,29 +405,25 @@ static __device__ __forceinline__ f32x4 pp_mma(const bf16x8& wv, const bf16x8& a
 #define SC_PP_BARRIER_VM(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 #define SC_PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int D, int DBG = 0, class TailHook = NoTailHook, bool I8 = false>
+// PREF: half-tiles 0 .. 7 of this tile were requested before the call (K >= 192); par: ring parity of K-tile 0 (0 unless the caller chains
+// tiles with an odd number of K-tiles: the next tile then starts at par ^ 1)
+template <int D, int DBG = 0, class TailHook = NoTailHook, bool I8 = false, bool PREF = false>
 static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ W, int ldw,
                                                                  int n0, int K, char* smem, f32x4 (&acc)[4][8], int w, int lane,
-                                                                 TailHook tail = TailHook{}, size_t a_kstep = G_BK) {
+                                                                 TailHook tail = TailHook{}, size_t a_kstep = G_BK, int par = 0) {
     static_assert(D >= 2 && D <= 5, "half-tiles in flight");
     constexpr bool HOOK = !std::is_same<TailHook, NoTailHook>::value;
     constexpr bool COOP = TailHook::kCoop;
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
-    const int coop0 = (nk & 1) * 4 + 7;  // slot read in phase Q - 2 of the last two K-tiles: (coop0 + Q) & 7
+    const int coop0 = ((nk + par) & 1) * 4 + 7;  // slot read in phase Q - 2 of the last two K-tiles: (coop0 + Q) & 7
     // sources: buffer descriptors (base + 32-bit per-lane offset + scalar K offset: no 64-bit vector arithmetic per piece)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, -1, 0x00020000);
     const uint32_t a_kbytes = (uint32_t)(a_kstep * 2), a1_off = (uint32_t)(64 * lda * 2), w1_off = (uint32_t)(32 * ldw * 2);
     uint32_t va[2], vw[2];  // byte offsets of this lane's 16 bytes in the wave's two pieces (8 rows x 128 B each) of an A / W half-tile
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int lr = (2 * w + i) * 8 + (lane >> 3), pos = lane & 7;
-        const int c = pos ^ ((lr >> 1) & 7);  // LDS-DMA writes linearly: the swizzle is applied on the source address
-        va[i] = (uint32_t)(((lr >> 6) * 128 + (lr & 63)) * lda * 2 + c * 16);
-        vw[i] = (uint32_t)(((lr >> 5) * 64 + (lr & 31)) * ldw * 2 + c * 16);
-    }
+    pp_piece_offsets(lda, ldw, w, lane, va, vw);
     // fragment rows of this lane inside an A / W half-tile image (k-step 0; k-step 1 = the same address ^ 64)
     const uint32_t rd_sw = (uint32_t)(fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4));
     const uint32_t a_rd = (uint32_t)(wm * 64 * 128) + rd_sw, w_rd = (uint32_t)(wn * 32 * 128) + rd_sw;
@@ -395,7 +431,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
     bf16x8 fa0[4][2], fa1[4][2], fw0[2][2], fw1[2][2];
     auto stage = [&](int t, int j) {  // request this wave's two pieces of half-tile j of K-tile t
         if (DBG & 1) return;
-        char* dst = smem + (((t & 1) * 4 + j) * 16384 + 2 * w * 1024);
+        char* dst = smem + ((((t + par) & 1) * 4 + j) * 16384 + 2 * w * 1024);
         if (j == 1 || j == 2) {
             const uint32_t so = (uint32_t)t * a_kbytes + (j == 2 ? a1_off : 0u);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)dst, 16, va[0], so, 0, 0);
@@ -408,7 +444,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
     };
     auto rdA = [&](bf16x8 (&dst)[4][2], int t, int j) {
         if (DBG & 4) return;
-        const char* b = smem + (uint32_t)((t & 1) << 16);
+        const char* b = smem + (uint32_t)(((t + par) & 1) << 16);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -416,7 +452,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
     };
     auto rdW = [&](bf16x8 (&dst)[2][2], int t, int j) {
         if (DBG & 4) return;
-        const char* b = smem + (uint32_t)((t & 1) << 16);
+        const char* b = smem + (uint32_t)(((t + par) & 1) << 16);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -438,36 +474,40 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
     };
 
     // prologue: half-tiles 0 .. D + 1 requested, 0 and 1 (W0, A0 of K-tile 0) landed and visible, W0(0) in registers
+    if (!PREF) {
 #pragma unroll
-    for (int h = 0; h <= D + 1; ++h) {
-        const bool keep = DBG & 1;  // (the ablation drops the in-loop requests only)
-        if (!keep) stage(h >> 2, h & 3);
-        else {
-            char* dst = smem + (((h >> 2) & 1) * 4 + (h & 3)) * 16384 + 2 * w * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)dst, 16, vw[0], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(dst + 1024), 16, vw[1], 0, 0, 0);
+        for (int h = 0; h <= D + 1; ++h) {
+            const bool keep = DBG & 1;  // (the ablation drops the in-loop requests only)
+            if (!keep) stage(h >> 2, h & 3);
+            else {
+                char* dst = smem + (((h >> 2) & 1) * 4 + (h & 3)) * 16384 + 2 * w * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)dst, 16, vw[0], 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(dst + 1024), 16, vw[1], 0, 0, 0);
+            }
         }
+        SC_PP_BARRIER_VM(2 * D);
+    } else {
+        SC_PP_BARRIER_VM(12);  // half-tiles 2 .. 7 may fly
     }
-    SC_PP_BARRIER_VM(2 * D);
     rdW(fw0, 0, 0);
     if (wm) SC_PP_BARRIER();  // wave group 1 runs one barrier behind group 0 from here on
     __builtin_amdgcn_sched_barrier(0);
 
-    // MODE 0: K-tiles 0 .. nk - 3 (every request exists); 1: K-tile nk - 2; 2: K-tile nk - 1
+    // MODE 0: K-tiles 0 .. nk - 3 (every request exists); 1: K-tile nk - 2; 2: K-tile nk - 1; 3: K-tile 0 behind a prefetch (PREF)
     auto ktile = [&](int t, auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
         auto phase = [&](auto p_c) {
             constexpr int p = decltype(p_c)::value;
             constexpr int hs = p + D + 2;  // the half-tile requested in this phase, relative to 4 t
-            constexpr bool ST = MODE == 0 || (MODE == 1 && hs < 8);
+            constexpr bool ST = MODE == 0 || (MODE == 1 && hs < 8) || (MODE == 3 && hs >= 8);
             // Q: phase number within the last two K-tiles.  Pairs of pieces that may stay in flight behind this phase's wait (the
             // half-tile read in phase Q + 1 was requested in phase Q - D and must have landed; everything younger may fly): the
             // K-tiles' own requests of phases Q - D + 1 .. Q (they end with phase 5 - D) and, with a cooperative hook, its
             // requests of phases max(1, Q - D) .. min(Q, 7).
-            constexpr int Q = MODE == 0 ? -8 : MODE == 1 ? p : 4 + p;
-            constexpr int NST = MODE == 0 ? D : ((Q < 5 - D ? Q : 5 - D) - Q + D > 0 ? (Q < 5 - D ? Q : 5 - D) - Q + D : 0);
+            constexpr int Q = (MODE == 0 || MODE == 3) ? -8 : MODE == 1 ? p : 4 + p;
+            constexpr int NST = MODE == 0 ? D : MODE == 3 ? (5 - p > D ? 5 - p : D) : ((Q < 5 - D ? Q : 5 - D) - Q + D > 0 ? (Q < 5 - D ? Q : 5 - D) - Q + D : 0);
             constexpr int RLO = Q - D > 1 ? Q - D : 1, RHI = Q < 7 ? Q : 7;
-            constexpr int NRES = (COOP && MODE != 0 && RHI >= RLO) ? RHI - RLO + 1 : 0;
+            constexpr int NRES = (COOP && (MODE == 1 || MODE == 2) && RHI >= RLO) ? RHI - RLO + 1 : 0;
             constexpr int FL = NST + NRES;
             // ---- LOAD segment
             if (p == 0) rdA(fa0, t, 1);
@@ -475,7 +515,7 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
             if (p == 2) rdW(fw1, t, 3);
             if (p == 3 && MODE != 2) rdW(fw0, t + 1, 0);
             if (ST) stage(t + (hs >> 2), hs & 3);
-            if (COOP && Q >= 1) tail.coop((coop0 + Q) & 7);
+            if (COOP && Q >= 1) tail.coop((coop0 + Q) & 7, Q - 1, va, vw);
             if (MODE == 2 && p == 3) tail();
             if (MODE == 2 && p == 2 && HOOK) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the hook rewrites slots other waves read
             if (MODE == 2 && p >= 2) SC_PP_BARRIER();  // (nothing of the K-tiles is in flight any more)
@@ -500,10 +540,14 @@ static __device__ __forceinline__ void gemm_tile256_mainloop_pp(const bf16_t* __
         phase(std::integral_constant<int, 3>{});
     };
     int t = 0;
+    if (PREF) {
+        ktile(0, std::integral_constant<int, 3>{});
+        t = 1;
+    }
 #pragma unroll 1
     for (; t + 2 < nk; ++t) ktile(t, std::integral_constant<int, 0>{});
     tail.prepare();
     ktile(t, std::integral_constant<int, 1>{});
     ktile(t + 1, std::integral_constant<int, 2>{});
-    if (COOP) tail.coop((coop0 + 8) & 7);  // the slot of the last half-tile read
+    if (COOP) tail.coop((coop0 + 8) & 7, 7, va, vw);  // the slot of the last half-tile read
 }

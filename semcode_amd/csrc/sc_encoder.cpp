@@ -669,6 +669,17 @@ extern "C" sc_status sc_diag_gemm_bf16(sc_runtime* rt, int32_t epi, const float*
 
 void sc_launch_gemm_i8_diag(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s);
 
+void sc_scan_set_coarse_workgroups(int v);
+void sc_scan_set_coarse_persistent(int v);
+extern "C" sc_status sc_diag_set_option(const char* name, int32_t value) {
+    if (!name) return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: NULL name");
+    if (!strcmp(name, "coarse_workgroups")) sc_scan_set_coarse_workgroups(value);
+    else if (!strcmp(name, "coarse_persistent")) sc_scan_set_coarse_persistent(value);
+    else if (!strcmp(name, "gemm_pp")) sc_gemm_set_pp(value);
+    else return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: unknown option '%s'", name);
+    return SC_OK;
+}
+
 extern "C" sc_status sc_diag_gemm_i8(sc_runtime* rt, const int8_t* A, const int8_t* W, int32_t M, int32_t N, int32_t K, int32_t* out) {
     if (!rt || !A || !W || !out) return sc_fail(SC_ERR_INVALID, "sc_diag_gemm_i8: NULL argument");
     if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % 128)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_gemm_i8: need M%%256==0, N%%256==0, K%%128==0");

@@ -308,7 +308,7 @@ static __device__ __forceinline__ void coarse256_coords(const CoarseArgs& a, int
 // precise test (0.46 us of that is wave skew, ~1.9 us the 32 bound tests: a wave64 VALU instruction issues over 4 cycles and two
 // waves share a SIMD), the two-phase form at 3.4-3.7 / 5.5-6.2 us -- its loop body costs more per entered group than 32 unrolled
 // copies do.  Removing the returning atomics changed nothing (4.3 vs 4.4 us).
-template <int METRIC, bool I8 = false, bool TRACE = false, bool NOATOM = false, bool NOPRECISE = false>
+template <int METRIC, bool I8 = false, bool TRACE = false, bool NOATOM = false, bool NOPRECISE = false, bool ROWTEST_OFF = false>
 static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
                                                           int lane) {
     const int wm = w >> 2, wn = w & 3;
@@ -352,6 +352,26 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         int Ti = 0;
         if (I8) Ti = !(Tlb == Tlb) ? (int)0x80000000 : Tlb <= -2.0e9f ? (int)0x80000000 : Tlb >= 2.0e9f ? 0x7FFFFFFF : (int)Tlb - 1;
         if (!I8 && !(Tlb == Tlb)) Tlb = -__builtin_inff();  // NaN (0 * inf on an all-zero row): let the precise test decide
+        // Round 3: first ONE test per row block -- the maximum of the lane's 16 scores (8 v_max3) against the bound, one wave-uniform
+        // branch per 16 x 64 scores instead of four; the per-group tests below run only for the row blocks that pass (15-45 % of
+        // them).  The bound tests were 1.9 us of a 3.4-4.4 us epilogue at ~28 vector instructions per row block (a wave64
+        // instruction issues over 4 cycles, two waves share a SIMD); the common path is now 9.
+        {
+            bool any_mi;
+            if (I8) {
+                int mx = max(max(__float_as_int(acc[0][mi][0]), __float_as_int(acc[0][mi][1])), max(__float_as_int(acc[0][mi][2]), __float_as_int(acc[0][mi][3])));
+#pragma unroll
+                for (int ni = 1; ni < 4; ++ni)
+                    mx = max(max(mx, max(__float_as_int(acc[ni][mi][0]), __float_as_int(acc[ni][mi][1]))), max(__float_as_int(acc[ni][mi][2]), __float_as_int(acc[ni][mi][3])));
+                any_mi = mx >= Ti;
+            } else {
+                float mx = fmaxf(fmaxf(acc[0][mi][0], acc[0][mi][1]), fmaxf(acc[0][mi][2], acc[0][mi][3]));
+#pragma unroll
+                for (int ni = 1; ni < 4; ++ni) mx = fmaxf(fmaxf(mx, fmaxf(acc[ni][mi][0], acc[ni][mi][1])), fmaxf(acc[ni][mi][2], acc[ni][mi][3]));
+                any_mi = mx >= Tlb;
+            }
+            if (!__any(any_mi) && !ROWTEST_OFF) continue;
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             // one uniform branch per group of 4 scores; taken by ~1 group in 500 once thresholds are tight
@@ -824,6 +844,80 @@ void sc_launch_query_i8(const float* Qp, int Q, int Qpad, int ld, int ld8, void*
 int sc_batched_kprime(void) { return KPRIME; }
 int sc_batched_kprime8(void) { return KPRIME8; }
 
+// ---- persistent form: one workgroup per CU walks its share of the tiles, and the LDS ring never drains between them: the last
+// phases of a tile request the first two K-tiles of the NEXT tile into the slots that fall free (gemm_tile.h, PPNextTileHook), so
+// a tile's first bytes (HBM latency: the corpus rows are read once) and a third of its fill travel under the previous tile's
+// tail and threshold epilogue.  A tile is 6 (int8) or 12 (bf16) K-tiles at 768 dimensions: with one workgroup per launch slot the
+// stamps read entry -> main loop done 11.6 us for 6.1 us of MFMAs, epilogue 4.2, 0.5 to the next workgroup
+// (profiles/r3g_coarse_trace.log).  Tiles: XCD x owns a contiguous range of logical tiles (as xcd_remap gives it); its G / 8
+// workgroups take consecutive tiles of it per round, i.e. one group of 8 row panels x 4 query tiles runs on one XCD at a time, as
+// under hardware dispatch.  The per-tile thresholds / norms in LDS are double buffered (a wave may be a whole epilogue ahead).
+static int g_coarse_wgs = 0, g_coarse_persistent = 1;  // sc_diag_set_option
+void sc_scan_set_coarse_workgroups(int v) { g_coarse_wgs = v; }
+void sc_scan_set_coarse_persistent(int v) { g_coarse_persistent = v; }
+#define COARSE_QLDS_BYTES (6 * 256 * 4)
+#define COARSEP_LDS_BYTES (4 * T_TILE_BYTES + 2 * COARSE_QLDS_BYTES)
+template <int METRIC, bool I8, bool TRACE = false>
+__global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this workgroup's tiles: lo + idx, lo + idx + per_round, ... below hi
+    const int G = (int)gridDim.x, x = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_round = G >> 3;
+    const int q8 = a.ntiles >> 3, r8 = a.ntiles & 7;
+    const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, hi = lo + (x < r8 ? q8 + 1 : q8);
+    int tile = lo + idx;
+    if (tile >= hi) return;
+    const int nk = a.ld / G_BK;
+    uint32_t va[2], vw[2];
+    pp_piece_offsets(a.ld, a.ld, w, lane, va, vw);
+    PPNextTileHook hook;
+    hook.a_kbytes = (uint32_t)(G_BK * 2); hook.a1_off = (uint32_t)(64 * a.ld * 2); hook.w1_off = (uint32_t)(32 * a.ld * 2);
+    hook.w = w; hook.smem = smem;
+    int64_t m0;
+    int n0;
+    coarse256_coords(a, tile, m0, n0);
+    hook.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Xb + m0 * a.ld), 0, -1, 0x00020000);
+    hook.rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Qb + (size_t)n0 * a.ld), 0, -1, 0x00020000);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) hook.coop(h, h, va, vw);  // the first tile's first two K-tiles, in ring order from parity 0
+    int par = 0, it = 0;
+#pragma unroll 1
+    for (;; ++it) {
+        char* smem_q = smem + (it & 1) * COARSE_QLDS_BYTES;  // this tile's thresholds / norms (the other copy may still be read)
+        coarse256_stage<I8>(a, m0, n0, smem_q, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int next = tile + per_round;
+        const bool more = next < hi;
+        int64_t m0n = m0;
+        int n0n = n0;
+        if (more) coarse256_coords(a, next, m0n, n0n);  // the last tile "prefetches" itself: the request counts of the loop stay what they are
+        hook.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Xb + m0n * a.ld), 0, -1, 0x00020000);
+        hook.rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Qb + (size_t)n0n * a.ld), 0, -1, 0x00020000);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (TRACE && tid == 0) {
+            a.trace[(size_t)tile * 8 + 0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            a.trace[(size_t)tile * 8 + 1] = (unsigned long long)wall_clock64();
+        }
+        gemm_tile256_mainloop_pp<4, 0, PPNextTileHook, I8, true>(a.Xb + m0 * a.ld, a.ld, 0, a.Qb, a.ld, n0, a.ld, smem, acc, w, lane, hook, G_BK, par);
+        par ^= nk & 1;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (TRACE && tid == 0) a.trace[(size_t)tile * 8 + 2] = (unsigned long long)wall_clock64();
+        coarse256_epilogue<METRIC, I8>(a, acc, m0, n0, smem_q, w, lane);
+        if (TRACE && tid == 0) a.trace[(size_t)tile * 8 + 3] = (unsigned long long)wall_clock64();
+        if (!more) break;
+        tile = next;
+        m0 = m0n;
+        n0 = n0n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's self-prefetch must not outlive the workgroup's LDS
+}
+
 template <int METRIC, bool I8>
 static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
     static const char* env = getenv("SC_COARSE_PP");  // A/B: 0 = the one-barrier main loop
@@ -833,6 +927,21 @@ static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
         attr = true;
+    }
+    static const char* envp = getenv("SC_COARSE_PERSIST");  // A/B: 0 = one workgroup per tile
+    static const bool persist_env = envp ? atoi(envp) != 0 : true;
+    if (pp && persist_env && g_coarse_persistent && a.ld >= 3 * G_BK) {
+        static int cus8 = 0;
+        if (!cus8) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            const int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+            cus8 = cus >= 8 ? (cus & ~7) : 8;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256p_kernel<METRIC, I8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSEP_LDS_BYTES);
+        }
+        const int wgs = g_coarse_wgs > 0 ? ((g_coarse_wgs + 7) & ~7) : cus8;  // a multiple of 8: blocks b, b + 8, ... share an XCD
+        hipLaunchKernelGGL((scan_coarse256p_kernel<METRIC, I8>), dim3((unsigned)wgs), dim3(512), COARSEP_LDS_BYTES, s, a);
+        return;
     }
     if (pp && a.ld >= 2 * G_BK) hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 4>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 0>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
@@ -849,7 +958,10 @@ static void coarse256_trace(CoarseArgs a, bool i8, hipStream_t s) {
     (void)hipMemsetAsync(dev, 0, words * 8, s);
     a.trace = dev;
     static const int mode = atoi(getenv("SC_COARSE_TRACE"));  // 1 trace, 2 trace without the returning atomics (results invalid)
-    if (i8 && mode == 3) {  // main loop only
+    if (i8 && mode == 5) {  // the persistent kernel: stamps of wave 0 per tile (entry = its own loop start)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256p_kernel<SC_METRIC_L2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSEP_LDS_BYTES);
+        hipLaunchKernelGGL((scan_coarse256p_kernel<SC_METRIC_L2, true, true>), dim3(256), dim3(512), COARSEP_LDS_BYTES, s, a);
+    } else if (i8 && mode == 3) {  // main loop only
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<SC_METRIC_L2, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
         hipLaunchKernelGGL((scan_coarse256_kernel<SC_METRIC_L2, 3, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
     } else if (i8 && mode == 4) {  // bound tests only

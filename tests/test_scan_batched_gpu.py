@@ -34,6 +34,33 @@ def test_batched_equals_oracle_100k(rt, metric, nq):
     ix.close()
 
 
+@pytest.mark.parametrize("dim,metric", [(768, "L2"), (768, "IP"), (768, "COSINE"), (448, "L2"), (192, "L2")])
+def test_persistent_coarse_kernel_walks_many_tiles_per_workgroup(rt, dim, metric):
+    """The coarse scan is a persistent kernel whose LDS ring prefetches the next tile's first two K-tiles (scan_coarse256p_kernel).
+    With the grid cut to 8 / 24 workgroups each one walks dozens of tiles -- even and odd K-tile counts (the ring parity flips
+    between tiles when odd: 448 dims = 7 bf16 K-tiles), both coarse stages -- and with one workgroup per tile (the non-persistent
+    kernel) the results are the same bits."""
+    X = orc.synth(60_000, dim, seed=41)
+    Q = orc.synth(300, dim, seed=42)  # two query tiles
+    od, orow = orc.search(X, Q, 10, metric)
+    ix = _native.Index(rt, dim, metric=metric)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    try:
+        for wgs, persistent in ((8, 1), (24, 1), (0, 1), (0, 0)):
+            _native.diag_set_option("coarse_workgroups", wgs)
+            _native.diag_set_option("coarse_persistent", persistent)
+            for stage in (8, 16):
+                ix.set_coarse_stage(stage)
+                d, r = ix.search(Q, k=10)
+                assert ix.last_search_stats()["path"] == "batched"
+                assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)), (wgs, persistent, stage)
+    finally:
+        _native.diag_set_option("coarse_workgroups", 0)
+        _native.diag_set_option("coarse_persistent", 1)
+        ix.close()
+
+
 @pytest.mark.parametrize("n", [1, 100, 127, 128, 129, 1000, 5000])
 def test_batched_small_and_ragged(rt, n):
     rng = np.random.default_rng(n)
