@@ -682,8 +682,11 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-        if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, r0, r1, ld8, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale);
-        else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s);
+        // a query keeps about KP of the r0 rows seen so far: a 256 x 256 tile of this phase about 65536 KP / r0 survivors -- above a few
+        // hundred the two-pass epilogue (one list-slot atomic per query and tile instead of one per survivor)
+        const bool dense = r0 < (int64_t)256 * KP;
+        if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, r0, r1, ld8, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale, dense);
+        else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, false, nullptr, nullptr, dense);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
         sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);

@@ -446,8 +446,98 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     if (nh > 3 && p3 < (unsigned)a.cap) a.surv[(size_t)(n0 + hq3) * a.cap + p3] = hk3;
 }
 
+// Epilogue for tiles in which MOST scores survive (the first phases of a batch: thresholds are still +inf or loose, a 256 x 256
+// tile yields thousands of survivors).  The epilogue above allocates a list slot per hit with a returning global atomic -- four
+// queued per lane, the rest one round trip each: the first six launches of a 10M-row batch (3.5 % of the rows) took 2.5 of its
+// 10.9 ms (gpurun_out/r3l: 500, 644, 411, 243, 286, 407 us; one 256-row tile with 9 400 hits 230 us).  Here a tile makes ONE global
+// atomic per query: pass 1 counts the hits per query in LDS (the pipeline buffers are dead), 256 threads reserve [base, base + n)
+// of each query's list, pass 2 re-evaluates the same tests and writes each hit at base + an LDS ticket.  Same survivor set as
+// the sparse epilogue (same tests, same arithmetic); the order inside a list differs, which the selection does not see.
+// Those six launches now take 86, 86, 64, 58, 198, 553 us (gpurun_out/r3n), the step 10.7 -> 9.1 ms.
+template <int METRIC, bool I8>
+static __device__ __forceinline__ void coarse256_epilogue_dense(const CoarseArgs& a, const f32x4 (&acc)[4][8], int64_t m0, int n0, char* smem, int w,
+                                                                int lane, int tid) {
+    const int wm = w >> 2, wn = w & 3;
+    asm volatile("" : "+v"(lane));
+    const float* q_tf = reinterpret_cast<const float*>(smem + COARSE_QLDS);
+    const float* q_thr = q_tf + 256;
+    const float* q_qn = q_tf + 512;
+    const float* x_xn = q_tf + 768;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem);  // [256] hits per local query, then the tickets of pass 2
+    unsigned* base = cnt + 256;                         // [256] first list slot of this tile's hits
+    const int fr = lane & 15, fq = lane >> 4;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is out of the main loop: the ring is free
+    if (tid < 256) cnt[tid] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    f32x4 tf[4], sq[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        tf[ni] = *reinterpret_cast<const f32x4*>(q_tf + wn * 64 + ni * 16 + 4 * fq);
+        if (I8) sq[ni] = *reinterpret_cast<const f32x4*>(q_tf + 1024 + wn * 64 + ni * 16 + 4 * fq);
+    }
+    // the tests of coarse256_epilogue, score by score: fast test, then the precise one; key valid when it returns true
+    auto hit = [&](int mi, int ni, int r, uint64_t& key) -> bool {
+        const int rl = wm * 128 + mi * 16 + fr;
+        const int64_t row = m0 + rl;
+        const float xn = x_xn[rl];
+        const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
+        const float sx = I8 ? q_tf[1280 + rl] : 0.f;
+        const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
+        const float accv = acc[ni][mi][r];
+        float t;
+        if (I8) {
+            const float av = (float)__float_as_int(accv) * ar;
+            t = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
+        } else {
+            if (METRIC == SC_METRIC_L2) t = fmaf(-2.0f, accv, xn);
+            else if (METRIC == SC_METRIC_COSINE) t = -accv * xs;
+            else t = -accv;
+        }
+        if (!(row < a.row1 && t <= tf[ni][r])) return false;
+        const int ql = wn * 64 + ni * 16 + 4 * fq + r;
+        const float dotv = I8 ? (float)__float_as_int(accv) * (sx * sq[ni][r]) : accv;
+        const float sc = sc_score<METRIC>(dotv, xn, q_qn[ql]);
+        const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
+        if (!(v <= q_thr[ql])) return false;
+        key = sc_make_key<METRIC>(sc, (uint32_t)row);
+        return true;
+    };
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint64_t key;
+                if (hit(mi, ni, r, key)) __hip_atomic_fetch_add(&cnt[wn * 64 + ni * 16 + 4 * fq + r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 256) {
+        const unsigned c = cnt[tid];
+        unsigned b = 0;
+        if (c) b = atomicAdd(a.count + n0 + tid, c);  // (padded queries never hit: their threshold is -inf)
+        base[tid] = b;
+        cnt[tid] = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint64_t key;
+                if (hit(mi, ni, r, key)) {
+                    const int ql = wn * 64 + ni * 16 + 4 * fq + r;
+                    const unsigned pos = base[ql] + __hip_atomic_fetch_add(&cnt[ql], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pos < (unsigned)a.cap) a.surv[(size_t)(n0 + ql) * a.cap + pos] = key;
+                }
+            }
+}
+
 // PP: 0 = one barrier per K-tile, 2..5 = the ping-pong main loop with that many half-tiles in flight (gemm_tile.h)
-template <int METRIC, int DBG = 0, bool I8 = false, int PP = 4>
+// DENSE: the two-pass epilogue above (launches whose tiles are expected to keep hundreds of survivors)
+template <int METRIC, int DBG = 0, bool I8 = false, int PP = 4, bool DENSE = false>
 __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -486,7 +576,8 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
         }
         return;
     }
-    coarse256_epilogue<METRIC, I8, (DBG & 2) != 0, (DBG & 4) != 0, (DBG & 8) != 0>(a, acc, m0, n0, smem, w, lane);
+    if constexpr (DENSE) coarse256_epilogue_dense<METRIC, I8>(a, acc, m0, n0, smem, w, lane, tid);
+    else coarse256_epilogue<METRIC, I8, (DBG & 2) != 0, (DBG & 4) != 0, (DBG & 8) != 0>(a, acc, m0, n0, smem, w, lane);
     if (DBG & 2) {
         __syncthreads();
         if (tid == 0) a.trace[(size_t)blockIdx.x * 8 + 3] = (unsigned long long)wall_clock64();
@@ -919,7 +1010,18 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
 }
 
 template <int METRIC, bool I8>
-static void launch_coarse256(const CoarseArgs& a, hipStream_t s) {
+static void launch_coarse256(const CoarseArgs& a, hipStream_t s, bool dense) {
+    static const char* envd = getenv("SC_COARSE_DENSE");  // A/B: 0 = the sparse epilogue everywhere
+    static const bool dense_ok = envd ? atoi(envd) != 0 : true;
+    if (dense && dense_ok && a.ld >= 2 * G_BK) {
+        static bool attr_d = false;
+        if (!attr_d) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
+            attr_d = true;
+        }
+        hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 4, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
+        return;
+    }
     static const char* env = getenv("SC_COARSE_PP");  // A/B: 0 = the one-barrier main loop
     static const bool pp = (env ? atoi(env) : 4) != 0;
     static bool attr = false;
@@ -1007,7 +1109,7 @@ static void coarse256_trace(CoarseArgs a, bool i8, hipStream_t s) {
 
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
-                           int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale) {
+                           int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale, bool dense) {
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = i8 ? ld / 2 : ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
     a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap; a.xscale = xscale; a.qscale = qscale;
@@ -1032,13 +1134,13 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
             return;
         }
         if (i8) {
-            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, true>(a, s);
-            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, true>(a, s);
-            else launch_coarse256<SC_METRIC_IP, true>(a, s);
+            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, true>(a, s, dense);
+            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, true>(a, s, dense);
+            else launch_coarse256<SC_METRIC_IP, true>(a, s, dense);
         } else {
-            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, false>(a, s);
-            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, false>(a, s);
-            else launch_coarse256<SC_METRIC_IP, false>(a, s);
+            if (metric == SC_METRIC_L2) launch_coarse256<SC_METRIC_L2, false>(a, s, dense);
+            else if (metric == SC_METRIC_COSINE) launch_coarse256<SC_METRIC_COSINE, false>(a, s, dense);
+            else launch_coarse256<SC_METRIC_IP, false>(a, s, dense);
         }
         return;
     }

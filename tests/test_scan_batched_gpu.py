@@ -40,7 +40,8 @@ def test_persistent_coarse_kernel_walks_many_tiles_per_workgroup(rt, dim, metric
     With the grid cut to 8 / 24 workgroups each one walks dozens of tiles -- even and odd K-tile counts (the ring parity flips
     between tiles when odd: 448 dims = 7 bf16 K-tiles), both coarse stages -- and with one workgroup per tile (the non-persistent
     kernel) the results are the same bits."""
-    X = orc.synth(60_000, dim, seed=41)
+    # (int8 stage: the per-wave hit lists of the persistent kernel exist from 256 x 512 = 131 072 rows up; bf16: from 32 768)
+    X = orc.synth(140_000 if (dim, metric) == (768, "L2") else 60_000, dim, seed=41)
     Q = orc.synth(300, dim, seed=42)  # two query tiles
     od, orow = orc.search(X, Q, 10, metric)
     ix = _native.Index(rt, dim, metric=metric)
