@@ -66,17 +66,45 @@ class Ctx:
     pass
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel sources of the library this process runs (semcode_amd/csrc/*.{hip,h,cpp}, names and contents):
+    what scripts/pmc_summary.py stamps into a PMC summary, so that a measured traffic figure can be tied to the code it was
+    measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "semcode_amd" / "csrc").iterdir()):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+_PMC = {}
+
+
 def pmc_traffic():
     """HBM-side bytes from the last committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on
     gfx950 for 16 B/lane streaming reads).  PMC counters cannot be read from inside this process, so these are
-    the committed figures of the same kernels on the same workload; None when the file is absent."""
+    the committed figures of the same kernels on the same workload -- and only when the summary was measured on THIS
+    library's kernel sources (its "csrc_sha" equals csrc_sha()): otherwise every traffic field is null and the note
+    says why.  None when no summary is committed."""
+    if "d" in _PMC:
+        return _PMC["d"]
+    d = None
     try:
         latest = sorted((ROOT / "profiles").glob("*_pmc_traffic.json"))[-1]  # named per round: the newest one
-        d = json.loads(latest.read_text())
-        d["_file"] = "profiles/" + latest.name
-        return d
+        raw = json.loads(latest.read_text())
+        have, want = raw.get("csrc_sha"), csrc_sha()
+        if have == want:
+            d = raw
+            d["_file"] = f"profiles/{latest.name} (measured on csrc {have}, commit {raw.get('commit', '?')})"
+        else:
+            d = {"_file": f"profiles/{latest.name} was measured on csrc {have or 'unstamped'}, this library is {want}: traffic not reported (re-run scripts/measure_round.sh)"}
     except Exception:
-        return None
+        d = None
+    _PMC["d"] = d
+    return d
 
 
 def timed(ctx, fn, nsteps):
@@ -96,6 +124,8 @@ def timed(ctx, fn, nsteps):
     t0 = time.perf_counter()
     for _ in range(nsteps):
         fn()
+    if getattr(ctx, "drain", None):
+        ctx.drain()  # rank 0: the last step's host merge
     torch.cuda.synchronize()
     if ctx.world > 1:
         barrier()
@@ -215,6 +245,32 @@ def bench_scan(ctx, args) -> dict:
 
             searcher = ShardedSearcher(ix, args.metric_type, comm=ctx.comm)
     rt.synchronize()
+    # The host-side final merge (north_star) runs on rank 0 only.  It is taken off the step's critical path: a worker thread merges
+    # step i's gathered lists (sc_topk_merge_host releases the GIL) while the device scans step i + 1; timed() drains it before
+    # the clock stops (merge_drain), and its own time is reported (host_merge_ms_per_step).
+    from concurrent.futures import ThreadPoolExecutor
+
+    merger = ThreadPoolExecutor(max_workers=1) if world > 1 and rank == 0 else None
+    pending = []
+    merge_time = [0.0, 0]
+
+    def host_merge(gd, gr):
+        t0 = time.perf_counter()
+        out = _native.topk_merge_host(args.metric_type, gd, gr)
+        merge_time[0] += time.perf_counter() - t0
+        merge_time[1] += 1
+        return out
+
+    def submit_merge(gd, gr):
+        while pending:  # at most one merge in flight behind the step that produced it
+            pending.pop().result()
+        pending.append(merger.submit(host_merge, gd.cpu().numpy(), gr.cpu().numpy()))
+
+    def merge_drain():
+        while pending:
+            pending.pop().result()
+
+    ctx.drain = merge_drain if merger else None
 
     def step(nq=Q):
         if world > 1 and ctx.comm is not None:
@@ -224,7 +280,7 @@ def bench_scan(ctx, args) -> dict:
             if rank == 0:
                 gd = all_d.view(-1)[: world * nq * k].view(world, nq, k)  # the gathered arrays are [world, nq, k] from the buffers' start
                 gr = all_r.view(-1)[: world * nq * k].view(world, nq, k)
-                return _native.topk_merge_host(args.metric_type, gd.cpu().numpy(), gr.cpu().numpy())
+                submit_merge(gd, gr)
             return None
         ix.search_dev(q.data_ptr(), nq, k, out_d.data_ptr(), out_r.data_ptr())
         if world > 1:  # no native communicator: torch.distributed carries the exchange
@@ -239,11 +295,13 @@ def bench_scan(ctx, args) -> dict:
                 ctx.dist.all_gather(lr, hr)
                 gd, gr = torch.stack(ld), torch.stack(lr)
             if rank == 0:
-                return _native.topk_merge_host(args.metric_type, gd.cpu().numpy(), gr.cpu().numpy())
+                submit_merge(gd, gr)
         return None
 
     for _ in range(args.warmup):
         step()
+    merge_drain()
+    merge_time[0], merge_time[1] = 0.0, 0
     rt.set_profiling(True)
     rt.profile_reset()
     dt = timed(ctx, step, args.steps)
@@ -270,9 +328,16 @@ def bench_scan(ctx, args) -> dict:
             t = timed(ctx, lambda: step(nq), args.steps)
             k_ms, k_n = rt.profile_read(0)
             rt.set_profiling(False)
-            p = ix.last_search_stats()["path"]
+            stq = ix.last_search_stats()
+            p = stq["path"]
+            # bytes the scan kernels actually stream per batch: the f32 rows (exact path: one pass per 16 queries), or the coarse shadow
+            # (batched path: int8 = 1 B, bf16 = 2 B per padded element)
+            ldq = (dim + 63) // 64 * 64
+            streamed = rows * ldq * 4 * ((nq + 15) // 16) if p == "exact" else rows * ((ldq + 127) // 128 * 128 if stq.get("coarse_bits", 16) == 8 else ldq * 2)
             sweep.append({"queries": nq, "path": p, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps * world / t,
-                          "scan_kernel_ms_per_batch": k_ms / args.steps, "corpus_gbs_per_gpu": rows * dim * 4 / (t / args.steps) / 1e9})
+                          "scan_kernel_ms_per_batch": k_ms / args.steps,
+                          "algorithmic_f32_gbs": rows * dim * 4 / (t / args.steps) / 1e9,  # SURVEY 8d's figure (f32 shard once per batch), NOT a memory rate
+                          "streamed_gbs": streamed / (t / args.steps) / 1e9, "streamed_bytes_per_batch": streamed})
             if p == "exact" and k_n and nq in (1, 16):
                 ach = rows * dim * 4 / (k_ms / k_n * 1e-3) / 1e9
                 cand = {"bound": "hbm", "kernel": "scan_exact_kernel", "queries": nq, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -326,6 +391,11 @@ def bench_scan(ctx, args) -> dict:
         "path": path, "uncertified_queries_last_step": unc,
         "roofline": roof,
     }
+    if world > 1:
+        res["host_merge_ms_per_step"] = (1e3 * merge_time[0] / merge_time[1]) if merge_time[1] else None  # rank 0, overlapped with the next step's scan
+    if merger:
+        merger.shutdown()
+    ctx.drain = None
     if sweep:
         res["sweep"] = sweep
     if exact_roof:
@@ -365,7 +435,30 @@ def cpu_baseline_scan(args) -> dict:
     t0 = time.perf_counter()
     cd, cr = orc.search(X[:crow], Q, args.k, args.metric_type)
     dtc = time.perf_counter() - t0
+    # BASELINE.md section 3, as written: numpy |x|^2 - 2 Q X^T (sgemm) + argpartition + stable argsort over 100 000 x 768 (default_rng(0)),
+    # 1 024 queries (default_rng(1)), k = 10, L2; 1 warm-up, median of 5, unscaled
+    import numpy as np
+
+    Xp = np.random.default_rng(0).standard_normal((100_000, 768), dtype=np.float32)
+    Qp = np.random.default_rng(1).standard_normal((1024, 768), dtype=np.float32)
+
+    def protocol_once():
+        t0 = time.perf_counter()
+        d2 = (Xp * Xp).sum(1)[None, :] - 2.0 * (Qp @ Xp.T)
+        part = np.argpartition(d2, 10, axis=1)[:, :10]
+        pd = np.take_along_axis(d2, part, axis=1)
+        order = np.lexsort((part, pd), axis=1)  # distance, then the lower row
+        np.take_along_axis(part, order, axis=1)
+        return time.perf_counter() - t0
+
+    protocol_once()
+    times = sorted(protocol_once() for _ in range(5))
+    tp = times[2]
+    protocol = {"value": 1024 / tp, "unit": "queries/s", "cores": cores, "seconds_per_batch": tp, "algorithmic_gbs": 100_000 * 768 * 4 / tp / 1e9,
+                "sample": "BASELINE.md section 3 protocol: numpy sgemm + argpartition + stable sort, 100 000 x 768 f32 (default_rng(0)), 1 024 queries (default_rng(1)), "
+                          "k = 10, L2; 1 warm-up, median of 5, unscaled (a 100x smaller corpus than the GPU leg's)"}
     return {"value": nq / (dt * (args.rows / rows)), "unit": "queries/s", "cores": cores, "kind": "port",
+            "baseline_md_protocol": protocol,
             "sample": f"sgemm + partial sort (torch CPU, f32) over {rows} of {args.rows} rows x all {nq} queries in {dt:.2f}s, scaled linearly in rows (exhaustive scan)",
             "canonical_port": {"value": nq / (dtc * (args.rows / crow)), "unit": "queries/s", "cores": orc.threads(),
                                "sample": f"scalar fmaf-chain C port (the parity oracle), {crow} rows x {nq} queries in {dtc:.2f}s, scaled linearly"}}
@@ -537,6 +630,9 @@ def main() -> None:
     }
     if ctx.collective:
         line["collective"] = ctx.collective
+    if ctx.comm is not None:
+        ci = ctx.comm.info()  # what the native communicator itself reports: proof that RCCL saw N ranks
+        line["rccl_ranks"], line["rccl_version"] = ci["world"], ci["rccl_version"]
     if embed:
         line.update({"value": embed["chunks_per_s"], "unit": "chunks/s", "ms_per_step": embed["ms_per_step"], "dtype": "bf16",
                      "config": {"workload": embed["workload"], "global_batch": args.batch * ctx.world, "seq_len": args.seq,

@@ -326,6 +326,8 @@ sc_status sc_comm_unique_id(void* id_out, size_t nbytes);
 sc_status sc_comm_create(sc_runtime* rt, int32_t rank, int32_t world, const void* unique_id, size_t nbytes, sc_comm** out);
 sc_status sc_comm_destroy(sc_comm* comm);
 sc_status sc_comm_info(sc_comm* comm, int32_t* rank, int32_t* world);
+/* ncclGetVersion of the RCCL copy this process bound (0 when that copy lacks the entry point). */
+sc_status sc_comm_rccl_version(int32_t* version);
 /* The search path's one exchange step: dist_dev / rows_dev [Q,k] of this rank (as written by sc_index_search_dev) ->
  * all_dist_dev / all_rows_dev [world,Q,k] on every rank (DEVICE pointers; asynchronous on the runtime's stream; both arrays
  * travel in one grouped RCCL launch). */

@@ -12,7 +12,20 @@ Separate passes per counter, kernel-trace/stats in yet another run, as the same 
 import argparse
 import collections
 import csv
+import hashlib
 import json
+import os
+from pathlib import Path
+
+
+def csrc_sha() -> str:
+    """the same hash bench.py computes (bench.csrc_sha): ties these figures to the kernel sources they were measured on"""
+    h = hashlib.sha256()
+    for f in sorted((Path(__file__).resolve().parent.parent / "semcode_amd" / "csrc").iterdir()):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path):
@@ -39,7 +52,8 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--note", default="")
 a = ap.parse_args()
 F, W = per_kernel(a.fetch), per_kernel(a.write)
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 1 --no-cpu-baseline`, "
+res = {"csrc_sha": csrc_sha(), "commit": os.environ.get("SC_COMMIT", "?"),
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 1 --no-cpu-baseline`, "
                  "MI355X; FETCH_SIZE doubled for 16 B/lane streaming reads as MI355X_MICROARCH.md prescribes; built by scripts/pmc_summary.py. " + a.note}
 g_f, g_w = pick(F, "gemm256_bf16_kernel"), pick(W, "gemm256_bf16_kernel")
 if g_f and g_w:
@@ -49,7 +63,7 @@ if g_f and g_w:
                                   "per_epilogue": {k.split("<")[1].split(",")[0]: {"fetch_x2": 2.0 * sum(v) / len(v), "launches": len(v)}
                                                    for k, v in F.items() if "gemm256_bf16_kernel<" in k}}
 steps = len(pick(F, "scan_rerank_kernel"))
-c_f, c_w = pick(F, "scan_coarse256_kernel"), pick(W, "scan_coarse256_kernel")
+c_f, c_w = pick(F, "scan_coarse256"), pick(W, "scan_coarse256")  # scan_coarse256_kernel (dense phases) + scan_coarse256p_kernel (persistent)
 if steps and c_f:
     res["scan_coarse256_kernel"] = {"steps": steps, "launches_per_step": len(c_f) / steps, "fetch_bytes_x2_per_step": 2.0 * sum(c_f) / steps,
                                     "write_bytes_per_step": (sum(c_w) / steps) if c_w else None}

@@ -107,6 +107,7 @@ SIGNATURES = {
     "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "sc_comm_destroy": (C.c_int32, [C.c_void_p]),
     "sc_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_comm_rccl_version": (C.c_int32, [C.POINTER(C.c_int32)]),
     "sc_comm_allgather_topk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sc_comm_broadcast": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     "sc_index_search_sharded": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -443,6 +444,13 @@ class Comm:
         if not self._h:
             raise RuntimeError("communicator is closed")
         return self._h
+
+    def info(self) -> dict:
+        """What the communicator itself reports (sc_comm_info, sc_comm_rccl_version): rank, world, RCCL version."""
+        r, w, v = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().sc_comm_info(self.handle, C.byref(r), C.byref(w)))
+        _check(lib().sc_comm_rccl_version(C.byref(v)))
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value}
 
     def allgather_topk(self, dist_ptr: int, rows_ptr: int, Q: int, k: int, all_dist_ptr: int, all_rows_ptr: int) -> None:
         _check(lib().sc_comm_allgather_topk(self.handle, C.c_void_p(dist_ptr), C.c_void_p(rows_ptr), int(Q), int(k),

@@ -611,12 +611,11 @@ static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, cons
     static const char* env = getenv("SC_ATTN_WAVES");  // A/B aid
     constexpr int NWD = KT >= 8 ? 8 : 4;
     const int nw = (env && KT >= 8) ? atoi(env) : NWD;
-    static bool done = false;
-    if (!done) {
+    static ScDeviceOnce once;  // per instantiation and device
+    sc_device_once(once, [&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + 4 * 1152);
         if (KT >= 8) hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<KT, ALIBI, NWD>), hipFuncAttributeMaxDynamicSharedMemorySize, KT * 32 * 256 + NWD * 1152);
-        done = true;
-    }
+    });
     const dim3 grid((unsigned)(H / 64), (unsigned)B);
     if (KT >= 8 && nw == 8)
         hipLaunchKernelGGL((attention_kernel<KT, ALIBI, NWD>), grid, dim3(NWD * 64), (size_t)KT * 32 * 256 + NWD * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx, blocked);

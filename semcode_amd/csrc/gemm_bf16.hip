@@ -585,11 +585,8 @@ __global__ __launch_bounds__(512) void gemm256_i8_diag_kernel(const int8_t* __re
         for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(out + (size_t)(mi * 16) * N + ni * 16) = acc[ni][mi];
 }
 void sc_launch_gemm_i8_diag(const void* A, const void* W, void* C, int M, int N, int K, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_i8_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
-        attr = true;
-    }
+    static ScDeviceOnce once;
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_i8_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES); });
     hipLaunchKernelGGL(gemm256_i8_diag_kernel, dim3((unsigned)((M / T_BM) * (N / T_BN))), dim3(512), T_LDS_BYTES, s, (const int8_t*)A, (const int8_t*)W, (int32_t*)C, M, N, K);
 }
 
@@ -678,11 +675,8 @@ static int gemm_pp() {
 }
 template <int EPI, int DBG, int PP>
 static void launch256_pp(const GemmArgs& a, dim3 grid, dim3 block, hipStream_t s) {
-    static bool attr = false;  // one per instantiation
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI, DBG, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
-        attr = true;
-    }
+    static ScDeviceOnce once;  // one per instantiation (and device)
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel<EPI, DBG, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES); });
     hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, DBG, PP>), grid, block, T_LDS_BYTES, s, a);  // 128 KiB pipeline + 18 KiB epilogue staging
 }
 template <int EPI, int DBG>
@@ -739,7 +733,6 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     a.order = env_order ? atoi(env_order) : g_gemm_order >= 0 ? g_gemm_order : ((size_t)N * (size_t)K * 2 <= ((size_t)8 << 20) ? 0 : 16);
     a.trace = g_gemm_trace;
     { static const char* env_nt = getenv("SC_GEMM_NT"); a.nt = env_nt ? atoi(env_nt) : ((size_t)M * (size_t)N * 2 >= ((size_t)64 << 20)); }
-    static bool attr_done = false;
     if ((M % T_BM) == 0 && (N % T_BN) == 0 && !g_force_tile128) {
         a.tiles_n = N / T_BN;
         a.ntiles = (M / T_BM) * a.tiles_n;
@@ -747,21 +740,12 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
         a.splitk = 1;
         a.partial = nullptr;
         if (splitk_scratch && !g_gemm_dbg && !g_gemm_trace) {
-            static int cus = 0;
-            if (!cus) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-            }
-            const int d = sc_gemm_splitk_factor(M, N, K, cus);
+            const int d = sc_gemm_splitk_factor(M, N, K, sc_device_cus());
             if (d > 1 && (size_t)d * M * N * sizeof(float) <= splitk_scratch_bytes) {
                 a.splitk = d;
                 a.partial = (float*)splitk_scratch;
-                static bool attr_sk = false;
-                if (!attr_sk) {
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_splitk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES);
-                    attr_sk = true;
-                }
+                static ScDeviceOnce once_sk;
+                sc_device_once(once_sk, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_splitk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T_LDS_BYTES); });
                 hipLaunchKernelGGL(gemm256_splitk_kernel, dim3((unsigned)(a.ntiles * d)), block, T_LDS_BYTES, s, a);
                 const int rb = (int)std::min<int64_t>(((int64_t)M * (N / 4) + 255) / 256, 1024);
                 if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<EPI_BIAS_GELU>, dim3((unsigned)rb), dim3(256), 0, s, a);
@@ -785,12 +769,12 @@ void sc_launch_gemm_bf16(int epi, const void* A, int lda, const void* W, int ldw
     a.tiles_n = N / G_BN;
     a.ntiles = (M / G_BM) * a.tiles_n;
     const size_t lds = 4 * G_TILE_BYTES;  // 64 KiB
-    if (!attr_done) {
+    static ScDeviceOnce once128;
+    sc_device_once(once128, [&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BIAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     dim3 grid((unsigned)a.ntiles), block(256);
     if (epi == EPI_BIAS_GELU) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_GELU>, grid, block, lds, s, a);
     else if (epi == EPI_BIAS_RES) hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_RES>, grid, block, lds, s, a);

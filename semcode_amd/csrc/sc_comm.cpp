@@ -32,6 +32,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;  // optional
     const char* error = nullptr;
 };
 
@@ -60,6 +61,7 @@ Rccl* rccl() {
         SC_SYM(GroupEnd, "ncclGroupEnd")
         SC_SYM(GetErrorString, "ncclGetErrorString")
 #undef SC_SYM
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
     });
     return &r;
 }
@@ -70,6 +72,7 @@ struct sc_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     double* scratch = nullptr;  // device: one double for sc_comm_allreduce_max
+    int64_t* xchg = nullptr;    // device: [world][2] status words exchanged next to every collective of the sharded calls
     std::mutex mu;
 };
 
@@ -113,7 +116,8 @@ extern "C" sc_status sc_comm_create(sc_runtime* rt, int32_t rank, int32_t world,
         delete c;
         return sc_fail(SC_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl()->GetErrorString(r));
     }
-    if (hipMalloc((void**)&c->scratch, 16) != hipSuccess) {
+    if (hipMalloc((void**)&c->scratch, 16) != hipSuccess || hipMalloc((void**)&c->xchg, (size_t)world * 16) != hipSuccess) {
+        hipFree(c->scratch);
         rccl()->CommDestroy(c->comm);
         delete c;
         return sc_fail(SC_ERR_NOMEM, "sc_comm_create: hipMalloc failed");
@@ -132,9 +136,20 @@ extern "C" sc_status sc_comm_destroy(sc_comm* c) {
     hipStreamSynchronize(c->rt->stream);
     if (c->comm) rccl()->CommDestroy(c->comm);
     hipFree(c->scratch);
+    hipFree(c->xchg);
     sc_runtime* rt = c->rt;
     delete c;
     sc_runtime_release(rt);
+    return SC_OK;
+}
+
+extern "C" sc_status sc_comm_rccl_version(int32_t* version) {
+    if (!version) return sc_fail(SC_ERR_INVALID, "sc_comm_rccl_version: NULL argument");
+    sc_status st = need_rccl();
+    if (st) return st;
+    int v = 0;
+    if (rccl()->GetVersion) SC_NCCL(rccl()->GetVersion(&v));
+    *version = v;
     return SC_OK;
 }
 
@@ -186,15 +201,69 @@ extern "C" sc_status sc_comm_allreduce_max(sc_comm* c, double* value) {
 
 // ------------------------------------------------------------------ the sharded search / build, one C-ABI call per rank
 
-static sc_status allgather_topk_unlocked(sc_comm* c, const float* d, const int64_t* r, size_t n, float* all_d, int64_t* all_r) {
+// A rank whose local step failed must still take part in the collective, or every other rank waits in it forever.  So each
+// sharded call exchanges a status word per rank IN THE SAME grouped launch as its payload, a failed rank sends sentinel rows
+// (worst distance, row -1: they lose every merge), and all ranks return the worst status after the exchange.
+// xchg[r] = {status of rank r, aux}.  The caller holds c->mu.
+static sc_status exchange_status_unlocked(sc_comm* c, int64_t status, int64_t aux, std::vector<int64_t>& all, bool in_group) {
+    hipStream_t s = c->rt->stream;
+    const int64_t mine[2] = {status, aux};
+    SC_HIP(hipMemcpyAsync(c->xchg + 2 * (size_t)c->rank, mine, 16, hipMemcpyHostToDevice, s));
+    SC_HIP(hipStreamSynchronize(s));  // `mine` is on this stack frame
+    ncclResult_t r = rccl()->AllGather(c->xchg + 2 * (size_t)c->rank, c->xchg, 2, ncclInt64, c->comm, s);
+    if (in_group) {  // the caller closes the group
+        SC_NCCL(r);
+        return SC_OK;
+    }
+    SC_NCCL(r);
+    all.resize(2 * (size_t)c->world);
+    SC_HIP(hipMemcpyAsync(all.data(), c->xchg, all.size() * 8, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return SC_OK;
+}
+static sc_status worst_status(sc_comm* c, const std::vector<int64_t>& all, sc_status mine, const char* what) {
+    for (int r = 0; r < c->world; ++r)
+        if (all[2 * (size_t)r] != 0) {
+            if (mine) return mine;  // this rank's own error text is already set
+            return sc_fail(SC_ERR_STATE, "%s: rank %d failed with status %lld", what, r, (long long)all[2 * (size_t)r]);
+        }
+    return SC_OK;
+}
+
+// local top-k -> this rank's slot (or sentinels if the local search failed) -> grouped all-gather of distances, rows and status
+static sc_status search_and_gather_locked(sc_index* ix, sc_comm* c, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* all_d,
+                                          int64_t* all_r, const char* what) {
+    hipStream_t s = ix->rt->stream;
+    const size_t n = (size_t)Q * k;
+    float* my_d = all_d + (size_t)c->rank * n;  // in-place all-gather: this rank's [Q,k] goes straight into its slot
+    int64_t* my_r = all_r + (size_t)c->rank * n;
+    const sc_status st_local = sc_search_dev_locked(ix, q_dev, Q, k, nprobe, my_d, my_r);
+    if (st_local) {  // sentinels: the worst score under this metric and row -1
+        const float worst = ix->metric == SC_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+        int bits;
+        memcpy(&bits, &worst, 4);
+        (void)hipGetLastError();
+        SC_HIP(hipMemsetD32Async((hipDeviceptr_t)my_d, bits, n, s));
+        SC_HIP(hipMemsetAsync(my_r, 0xFF, n * 8, s));
+    }
+    std::lock_guard<std::mutex> gc(c->mu);
+    std::vector<int64_t> all;
+    const int64_t mine[2] = {st_local, 0};
+    SC_HIP(hipMemcpyAsync(c->xchg + 2 * (size_t)c->rank, mine, 16, hipMemcpyHostToDevice, s));
+    SC_HIP(hipStreamSynchronize(s));
     SC_NCCL(rccl()->GroupStart());
-    ncclResult_t r1 = rccl()->AllGather(d, all_d, n, ncclFloat32, c->comm, c->rt->stream);
-    ncclResult_t r2 = rccl()->AllGather(r, all_r, n, ncclInt64, c->comm, c->rt->stream);
-    ncclResult_t r3 = rccl()->GroupEnd();
+    ncclResult_t r1 = rccl()->AllGather(my_d, all_d, n, ncclFloat32, c->comm, s);
+    ncclResult_t r2 = rccl()->AllGather(my_r, all_r, n, ncclInt64, c->comm, s);
+    ncclResult_t r3 = rccl()->AllGather(c->xchg + 2 * (size_t)c->rank, c->xchg, 2, ncclInt64, c->comm, s);
+    ncclResult_t r4 = rccl()->GroupEnd();
     SC_NCCL(r1);
     SC_NCCL(r2);
     SC_NCCL(r3);
-    return SC_OK;
+    SC_NCCL(r4);
+    all.resize(2 * (size_t)c->world);
+    SC_HIP(hipMemcpyAsync(all.data(), c->xchg, all.size() * 8, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    return worst_status(c, all, st_local, what);
 }
 
 extern "C" sc_status sc_index_search_sharded_dev(sc_index* ix, sc_comm* c, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe,
@@ -204,14 +273,7 @@ extern "C" sc_status sc_index_search_sharded_dev(sc_index* ix, sc_comm* c, const
     if (ix->rt != c->rt) return sc_fail(SC_ERR_INVALID, "sc_index_search_sharded_dev: index and communicator belong to different runtimes");
     std::lock_guard<std::mutex> g(ix->mu);
     SC_HIP(hipSetDevice(ix->rt->device));
-    // this rank's [Q,k] goes straight into its slot of the gathered arrays (in-place all-gather)
-    const size_t n = (size_t)Q * k;
-    float* my_d = all_dist_dev + (size_t)c->rank * n;
-    int64_t* my_r = all_rows_dev + (size_t)c->rank * n;
-    sc_status st = sc_search_dev_locked(ix, q_dev, Q, k, nprobe, my_d, my_r);
-    if (st) return st;
-    std::lock_guard<std::mutex> gc(c->mu);
-    return allgather_topk_unlocked(c, my_d, my_r, n, all_dist_dev, all_rows_dev);
+    return search_and_gather_locked(ix, c, q_dev, Q, k, nprobe, all_dist_dev, all_rows_dev, "sc_index_search_sharded_dev");
 }
 
 extern "C" sc_status sc_index_search_sharded(sc_index* ix, sc_comm* c, const float* q, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
@@ -227,21 +289,31 @@ extern "C" sc_status sc_index_search_sharded(sc_index* ix, sc_comm* c, const flo
         SC_HIP(hipSetDevice(ix->rt->device));
         hipStream_t s = ix->rt->stream;
         const size_t qb = ((size_t)Q * ix->dim * 4 + 255) & ~(size_t)255, db = (W * n * 4 + 255) & ~(size_t)255;
+        // (the staging buffer is the one allocation in front of the collective that can fail on ONE rank: sc_comm_create reserves
+        // nothing for it because its size depends on the call; a rank that cannot get it still has to answer the others)
         sc_status st = sc_grow(ix, (void**)&ix->io, &ix->io_cap, qb + db + W * n * 8);
-        if (st) return st;
+        if (st) {
+            // no room for the gathered arrays: take part with the status word alone would leave the payload gathers unmatched, so
+            // this rank reports through the status exchange of a zero-payload round -- every rank runs the same two rounds
+            std::lock_guard<std::mutex> gc(c->mu);
+            std::vector<int64_t> all;
+            (void)exchange_status_unlocked(c, st, 0, all, false);
+            return st;
+        }
+        {
+            std::lock_guard<std::mutex> gc(c->mu);
+            std::vector<int64_t> all;
+            sc_status ex = exchange_status_unlocked(c, 0, 0, all, false);  // round 1: did every rank get its staging buffer?
+            if (ex) return ex;
+            ex = worst_status(c, all, SC_OK, "sc_index_search_sharded (staging buffer)");
+            if (ex) return ex;
+        }
         float* dq = (float*)ix->io;
         float* all_d = (float*)((char*)ix->io + qb);
         int64_t* all_r = (int64_t*)((char*)ix->io + qb + db);
         SC_HIP(hipMemcpyAsync(dq, q, (size_t)Q * ix->dim * 4, hipMemcpyHostToDevice, s));
-        float* my_d = all_d + (size_t)c->rank * n;
-        int64_t* my_r = all_r + (size_t)c->rank * n;
-        st = sc_search_dev_locked(ix, dq, Q, k, nprobe, my_d, my_r);
+        st = search_and_gather_locked(ix, c, dq, Q, k, nprobe, all_d, all_r, "sc_index_search_sharded");
         if (st) return st;
-        {
-            std::lock_guard<std::mutex> gc(c->mu);
-            st = allgather_topk_unlocked(c, my_d, my_r, n, all_d, all_r);
-            if (st) return st;
-        }
         SC_HIP(hipMemcpyAsync(hd.data(), all_d, W * n * 4, hipMemcpyDeviceToHost, s));
         SC_HIP(hipMemcpyAsync(hr.data(), all_r, W * n * 8, hipMemcpyDeviceToHost, s));
         SC_HIP(hipStreamSynchronize(s));
@@ -256,37 +328,41 @@ extern "C" sc_status sc_index_train_sharded(sc_index* ix, sc_comm* c, int32_t ni
     if (c->world == 1) return sc_index_train(ix, niter, 0);
     SC_HIP(hipSetDevice(ix->rt->device));
     hipStream_t s = ix->rt->stream;
-    // header: {status of the root's training, nlist}; then the centroids, tight [nlist, dim] f32
     struct DevBuf {
         void* p = nullptr;
         ~DevBuf() { hipFree(p); }
-    } d_hdr, d_cent;
-    SC_HIP(hipMalloc(&d_hdr.p, 16));
-    int64_t hdr[2] = {0, 0};
-    std::vector<float> cent;
-    sc_status st_root = SC_OK;
-    if (c->rank == root) {
-        st_root = sc_index_train(ix, niter, 0);
-        int32_t nl = 0;
-        if (!st_root) st_root = sc_index_ivf_info(ix, &nl, nullptr, nullptr);
-        if (!st_root) {
-            cent.resize((size_t)nl * ix->dim);
-            st_root = sc_index_ivf_info(ix, &nl, cent.data(), nullptr);
-        }
-        hdr[0] = st_root;
-        hdr[1] = st_root ? 0 : nl;
-        SC_HIP(hipMemcpyAsync(d_hdr.p, hdr, 16, hipMemcpyHostToDevice, s));
+    } d_cent;
+    // Everything that can fail on ONE rank happens BEFORE the first collective, and its status is exchanged among all ranks: the
+    // centroid buffer (every rank knows the upper bound nlist x dim from its own handle) and, on the root, the training itself.
+    const size_t cap_bytes = (size_t)(ix->nlist > 0 ? ix->nlist : 1) * ix->dim * 4;
+    sc_status st_mine = SC_OK;
+    if (hipMalloc(&d_cent.p, cap_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        st_mine = sc_fail(SC_ERR_NOMEM, "sc_index_train_sharded: hipMalloc of the centroid buffer (%zu bytes) failed on rank %d", cap_bytes, c->rank);
     }
-    sc_status st = sc_comm_broadcast(c, d_hdr.p, 16, root);  // every rank takes part even when the root failed: no rank is left waiting
-    if (st) return st;
-    SC_HIP(hipMemcpyAsync(hdr, d_hdr.p, 16, hipMemcpyDeviceToHost, s));
-    SC_HIP(hipStreamSynchronize(s));
-    if (hdr[0] != 0) return c->rank == root ? st_root : sc_fail(SC_ERR_STATE, "sc_index_train_sharded: training failed on rank %d (status %lld)", root, (long long)hdr[0]);
-    const int nlist = (int)hdr[1];
+    std::vector<float> cent;
+    int32_t nl = 0;
+    if (c->rank == root && !st_mine) {
+        st_mine = sc_index_train(ix, niter, 0);
+        if (!st_mine) st_mine = sc_index_ivf_info(ix, &nl, nullptr, nullptr);
+        if (!st_mine && (size_t)nl * ix->dim * 4 > cap_bytes) st_mine = sc_fail(SC_ERR_STATE, "sc_index_train_sharded: trained nlist %d exceeds the handle's %d", nl, ix->nlist);
+        if (!st_mine) {
+            cent.resize((size_t)nl * ix->dim);
+            st_mine = sc_index_ivf_info(ix, &nl, cent.data(), nullptr);
+        }
+    }
+    std::vector<int64_t> all;
+    {
+        std::lock_guard<std::mutex> gc(c->mu);
+        sc_status ex = exchange_status_unlocked(c, st_mine, nl, all, false);  // every rank takes part, failed or not
+        if (ex) return ex;
+        ex = worst_status(c, all, st_mine, "sc_index_train_sharded");
+        if (ex) return ex;
+    }
+    const int nlist = (int)all[2 * (size_t)root + 1];
     const size_t bytes = (size_t)nlist * ix->dim * 4;
-    SC_HIP(hipMalloc(&d_cent.p, bytes));
     if (c->rank == root) SC_HIP(hipMemcpyAsync(d_cent.p, cent.data(), bytes, hipMemcpyHostToDevice, s));
-    st = sc_comm_broadcast(c, d_cent.p, bytes, root);  // the build's one collective (50 MB at 4096 x 3072)
+    sc_status st = sc_comm_broadcast(c, d_cent.p, bytes, root);  // the build's one collective (50 MB at 4096 x 3072)
     if (st) return st;
     if (c->rank == root) {
         SC_HIP(hipStreamSynchronize(s));  // cent goes out of scope

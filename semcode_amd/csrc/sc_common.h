@@ -5,6 +5,8 @@
 
 #include "../../include/semcode_hip.h"
 
+#include <mutex>
+
 #define SC_WAVE 64
 #define SC_LD_ALIGN 64            // corpus row stride is a multiple of 64 floats (256 B)
 #define SC_KEY_MAX 0xFFFFFFFFFFFFFFFFull
@@ -58,6 +60,39 @@ __host__ __device__ static inline float sc_key_score(int metric, uint64_t key) {
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
     float v = __builtin_bit_cast(float, u);
     return (metric == SC_METRIC_L2) ? v : -v;
+}
+
+// One-time, PER-DEVICE setup at a launch site.  hipFuncSetAttribute (the dynamic-LDS limit of a kernel) applies to the calling
+// thread's current device only, so a process-wide "done" flag leaves every other device at the 64 KiB default: one process could
+// not drive two devices (a service that owns a sharded collection).  Usage: static ScDeviceOnce once; sc_device_once(once, [&] { ... });
+struct ScDeviceOnce {
+    std::mutex mu;
+    uint64_t done[4] = {0, 0, 0, 0};
+};
+template <class F>
+static inline void sc_device_once(ScDeviceOnce& o, F&& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 255;
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (!((o.done[d >> 6] >> (d & 63)) & 1)) {
+        f();
+        o.done[d >> 6] |= 1ull << (d & 63);
+    }
+}
+// compute units of the calling thread's current device (cached per device)
+static inline int sc_device_cus() {
+    static std::mutex mu;
+    static int cus[256] = {0};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 255;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cus[d]) {
+        hipDeviceProp_t prop;
+        cus[d] = hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[d];
 }
 
 // ---- launchers implemented in the .hip files (all enqueue on `s`, never synchronise) ----

@@ -1014,33 +1014,23 @@ static void launch_coarse256(const CoarseArgs& a, hipStream_t s, bool dense) {
     static const char* envd = getenv("SC_COARSE_DENSE");  // A/B: 0 = the sparse epilogue everywhere
     static const bool dense_ok = envd ? atoi(envd) != 0 : true;
     if (dense && dense_ok && a.ld >= 2 * G_BK) {
-        static bool attr_d = false;
-        if (!attr_d) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
-            attr_d = true;
-        }
+        static ScDeviceOnce once_d;
+        sc_device_once(once_d, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES); });
         hipLaunchKernelGGL((scan_coarse256_kernel<METRIC, 0, I8, 4, true>), dim3((unsigned)a.ntiles), dim3(512), COARSE_LDS_BYTES, s, a);
         return;
     }
     static const char* env = getenv("SC_COARSE_PP");  // A/B: 0 = the one-barrier main loop
     static const bool pp = (env ? atoi(env) : 4) != 0;
-    static bool attr = false;
-    if (!attr) {
+    static ScDeviceOnce once;  // per instantiation and device
+    sc_device_once(once, [&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256_kernel<METRIC, 0, I8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSE_LDS_BYTES);
-        attr = true;
-    }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256p_kernel<METRIC, I8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSEP_LDS_BYTES);
+    });
     static const char* envp = getenv("SC_COARSE_PERSIST");  // A/B: 0 = one workgroup per tile
     static const bool persist_env = envp ? atoi(envp) != 0 : true;
     if (pp && persist_env && g_coarse_persistent && a.ld >= 3 * G_BK) {
-        static int cus8 = 0;
-        if (!cus8) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            const int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-            cus8 = cus >= 8 ? (cus & ~7) : 8;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse256p_kernel<METRIC, I8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COARSEP_LDS_BYTES);
-        }
+        const int cus = sc_device_cus(), cus8 = cus >= 8 ? (cus & ~7) : 8;
         const int wgs = g_coarse_wgs > 0 ? ((g_coarse_wgs + 7) & ~7) : cus8;  // a multiple of 8: blocks b, b + 8, ... share an XCD
         hipLaunchKernelGGL((scan_coarse256p_kernel<METRIC, I8>), dim3((unsigned)wgs), dim3(512), COARSEP_LDS_BYTES, s, a);
         return;
@@ -1148,13 +1138,12 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
     const int64_t rtiles = (row1 - row0 + G_BM - 1) / G_BM;
     a.ntiles = (int)(rtiles * a.qtiles);
     const size_t lds = 4 * G_TILE_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static ScDeviceOnce once128;
+    sc_device_once(once128, [&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    });
     dim3 grid((unsigned)a.ntiles), block(256);
     if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_coarse_kernel<SC_METRIC_L2>, grid, block, lds, s, a);
     else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_coarse_kernel<SC_METRIC_COSINE>, grid, block, lds, s, a);
@@ -1164,13 +1153,12 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
                            float* thr_fast, int* overflow, int Q, int kp, hipStream_t s) {
     const size_t lds = (size_t)(cap + kp) * 8 + (SEL_BINS + SEL_THREADS + 8) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static ScDeviceOnce once_sel;
+    sc_device_once(once_sel, [&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    });
     dim3 grid((unsigned)Q), block(SEL_THREADS);
     if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_L2>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow, kp);
     else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_select_kernel<SC_METRIC_COSINE>, grid, block, lds, s, surv, count, cap, best, qnorm, thr, thr_fast, overflow, kp);

@@ -652,11 +652,8 @@ bool sc_scan_listgemm_supported(int ld, int k) { return ld > 0 && (ld % SC_LD_AL
 
 template <int METRIC, int QB, int NW>
 static void launch_scan_listgemm(const ListGemmArgs& a, int groups, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_listgemm_kernel<METRIC, QB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static ScDeviceOnce once;  // per instantiation and device
+    sc_device_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_listgemm_kernel<METRIC, QB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     constexpr unsigned lds = LgLds<QB, NW>::total;
     hipLaunchKernelGGL((scan_listgemm_kernel<METRIC, QB, NW>), dim3((unsigned)groups), dim3(NW * 64), lds, s, a);
 }
@@ -721,11 +718,8 @@ bool sc_scan_exact_plan(int ld, int Q, int k, int cus, ScanPlan* p, int force_qt
 
 template <int METRIC, int QS>
 static void launch_scan_exact(const ScanArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<METRIC, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static ScDeviceOnce once;  // per instantiation and device
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_exact_kernel<METRIC, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL((scan_exact_kernel<METRIC, QS>), grid, dim3(256), lds, s, a);
 }
 

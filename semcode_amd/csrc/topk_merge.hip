@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void topk_tree_merge_kernel(int metr
     }
 }
 
-static bool g_tree_attr_done = false;
+static ScDeviceOnce g_tree_attr_once;
 
 // Lists whose 2 x k keys fit the LDS of one tree merge; more lists go through levels of such merges (chunks of SC_MERGE_FIT lists ->
 // one k-list each, written behind the partial lists: sc_topk_merge_scratch_bytes), which replaced a serial fallback that made
@@ -103,10 +103,7 @@ size_t sc_topk_merge_scratch_bytes(int lists, int Q, int k) {
 }
 void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int lists, int qt, int Q, int k, int64_t row_base,
                           float* out_dist, int64_t* out_rows, hipStream_t s) {
-    if (!g_tree_attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        g_tree_attr_done = true;
-    }
+    sc_device_once(g_tree_attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
     const int fit = merge_fit(k);
     const uint64_t* src = partial;
     // scratch of the levels: right behind the [groups][lists][qt][k] partial lists (the plan's partial_bytes includes it)
@@ -131,10 +128,7 @@ bool sc_topk_gather_merge_supported(int lists_per_query, int k) {
 
 void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int32_t* src, int lists_per_query, int Q, int k, int64_t row_base,
                                  float* out_dist, int64_t* out_rows, hipStream_t s) {
-    if (!g_tree_attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        g_tree_attr_done = true;
-    }
+    sc_device_once(g_tree_attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(topk_tree_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
     const size_t tree_lds = (size_t)2 * lists_per_query * k * sizeof(uint64_t);
     hipLaunchKernelGGL(topk_tree_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), tree_lds, s, metric, partial, lists_per_query, 1, Q, k,
                        row_base, out_dist, out_rows, src, 0, (uint64_t*)nullptr);

@@ -89,3 +89,45 @@ def test_concurrent_search_upsert_embed():
     for s in (store, ref):
         s.close()
     emb.close()
+
+
+def test_two_runtimes_in_one_process_interleave_searches():
+    """Several runtimes may live in one process (a service that owns a sharded collection: one runtime per device).  The launch
+    sites used to raise a kernel's dynamic-LDS limit behind process-wide flags; they are keyed by device now (sc_device_once).  This
+    box has one GPU, so the test runs two runtimes -- two streams -- on device 0 from two threads, every search path (exact, batched
+    int8 / bf16, IVF_FLAT probes), and checks each result against the CPU oracle."""
+    from oracle import sc_oracle as orc
+    from semcode_amd import _native
+
+    rts = [_native.Runtime(device=0), _native.Runtime(device=0)]
+    X = [orc.synth(30_000, 256, seed=61), orc.synth(20_000, 256, seed=62)]
+    Q = orc.synth(48, 256, seed=63)
+    want = [orc.search(x, Q, 10, "L2") for x in X]
+    idx = []
+    for rt, x in zip(rts, X):
+        ix = _native.Index(rt, 256, metric="L2")
+        ix.add(x)
+        idx.append(ix)
+    errors = []
+
+    def worker(i):
+        try:
+            ix = idx[i]
+            od, orow = want[i]
+            for rep in range(6):
+                for mode, nq in (("exact", 9), ("batched", 48), ("exact", 16), ("batched", 40)):
+                    ix.set_search_mode(mode)
+                    ix.set_coarse_stage(8 if rep % 2 else 16)
+                    d, r = ix.search(Q[:nq], k=10)
+                    assert np.array_equal(r, orow[:nq]) and np.array_equal(d.view(np.uint32), od[:nq].view(np.uint32)), (i, rep, mode)
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for ix in idx:
+        ix.close()
+    for rt in rts:
+        rt.close()
+    assert not errors, errors[0]
