@@ -58,7 +58,8 @@ def tensors_rows(tensors: dict, name: str) -> int:
 
 
 def load_weight_blob(path: "str | Path", layers: int, cfg: Optional[dict] = None) -> np.ndarray:
-    """Flat f32 blob in ABI order from `.npy` (already flat) or `.safetensors` (HF BERT names, or jina-bert-v2 names when the
+    """Flat f32 blob in ABI order from `.npy` (already flat), `.gguf` (llama.cpp's bert / jina-bert-v2 tensor names, F32 / F16 /
+    BF16; embeddings/gguf.py) or `.safetensors` (HF BERT names, or jina-bert-v2 names when the
     file holds `mlp.gated_layers`; optional "bert." prefix).  cfg: the encoder configuration the blob is for (checked
     against the checkpoint's architecture: a jina file needs alibi + geglu, a BERT file neither)."""
     path = Path(path)
@@ -88,7 +89,14 @@ def load_weight_blob(path: "str | Path", layers: int, cfg: Optional[dict] = None
                 else:
                     parts.append(get(f"encoder.layer.{l}.{n}"))
         return np.concatenate(parts)
-    raise ValueError(f"unsupported weight file {path} (use .npy blob or .safetensors)")
+    if path.suffix == ".gguf":  # the reference's local model format (settings.embedding_llamacpp_model_path): F32 / F16 / BF16 tensors
+        from .gguf import gguf_to_blob
+
+        blob, fcfg, _ = gguf_to_blob(path, cfg)
+        if fcfg["layers"] != layers:
+            raise ValueError(f"{path} has {fcfg['layers']} layers, the encoder configuration {layers}")
+        return blob
+    raise ValueError(f"unsupported weight file {path} (use .npy blob, .safetensors or .gguf)")
 
 
 class MI355XEmbeddings:
@@ -111,6 +119,14 @@ class MI355XEmbeddings:
             allow_synthetic = bool(getattr(settings, "mi355x_allow_synthetic", False))
         weights = weights if weights is not None else getattr(settings, "mi355x_weights_path", None)
         vocab = vocab if vocab is not None else getattr(settings, "mi355x_vocab_path", None)
+        # the reference's own local-model setting (settings.py:51, providers.py:77-99): a checkout that points it at a GGUF file keeps it
+        gguf_path = None
+        if weights is None:
+            cand = getattr(settings, "embedding_llamacpp_model_path", None)
+            if cand and str(cand).lower().endswith(".gguf"):
+                weights = cand
+        if isinstance(weights, (str, Path)) and str(weights).lower().endswith(".gguf"):
+            gguf_path = Path(weights)
         if weights is None and not allow_synthetic:
             raise ValueError("Set SEMCODE_MI355X_WEIGHTS_PATH (.safetensors or .npy blob) when using the mi355x embedding provider "
                              "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for random-init benchmark weights).")
@@ -119,6 +135,28 @@ class MI355XEmbeddings:
                              "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for the hash-tokenizer stand-in).")
         self._native = _native
         self._cfg = dict(_native.BERT_BASE)
+        self._vocab_tmp = None
+        if gguf_path is not None:  # the file states its own architecture, and carries the WordPiece vocabulary
+            from .gguf import gguf_config, gguf_vocab, read_gguf
+
+            meta, tens = read_gguf(gguf_path)
+            fcfg = gguf_config(meta)
+            fcfg["vocab"] = int(tens["token_embd.weight"][1][0])
+            fcfg["type_vocab"] = int(tens["token_types.weight"][1][0])
+            if fcfg["alibi"]:
+                fcfg["max_pos"] = max(int(fcfg["max_pos"]), int(self._cfg["max_pos"]))
+            elif "position_embd.weight" in tens:
+                fcfg["max_pos"] = int(tens["position_embd.weight"][1][0])
+            self._cfg.update(fcfg)
+            if vocab is None:
+                toks = gguf_vocab(meta)
+                if toks is not None:
+                    import tempfile
+
+                    self._vocab_tmp = tempfile.NamedTemporaryFile("w", suffix=".vocab.txt", encoding="utf-8", delete=False)
+                    self._vocab_tmp.write("\n".join(toks) + "\n")
+                    self._vocab_tmp.close()
+                    vocab = self._vocab_tmp.name
         self._cfg.update(cfg or {})
         self.max_tokens = min(self.max_tokens, self._cfg["max_pos"])
         self._fast_tokenizer: Any = None

@@ -36,7 +36,7 @@ def basic_split(text: str, lowercase: bool = True) -> List[str]:
     out = []
     for ch in text:
         cp = ord(ch)
-        if cp == 0 or cp == 0xFFFD or (unicodedata.category(ch) in ("Cc", "Cf") and ch not in "\t\n\r"):
+        if cp == 0 or cp == 0xFFFD or (unicodedata.category(ch).startswith("C") and ch not in "\t\n\r"):  # Cc, Cf, Cn, Co, Cs
             continue
         if _is_cjk(cp):
             out.append(f" {ch} ")
@@ -47,7 +47,9 @@ def basic_split(text: str, lowercase: bool = True) -> List[str]:
     words: List[str] = []
     for tok in "".join(out).split():
         if lowercase:
-            tok = tok.lower()
+            # code point by code point, as the Rust `tokenizers` normaliser and the C++ tokenizer do: str.lower() on the whole word
+            # applies the Greek final-sigma rule ("ΟΔΟΣ" -> "οδος"), they do not ("οδοσ")
+            tok = "".join(c.lower() for c in tok)
             tok = "".join(c for c in unicodedata.normalize("NFD", tok) if unicodedata.category(c) != "Mn")
         cur = ""
         for ch in tok:

@@ -124,5 +124,7 @@ class Retriever:
             self.last_error = exc
             return [[] for _ in questions]
         out = [[doc for doc in (hit_to_document(hit) for hit in hits) if doc] for hits in results]
-        self.last_error = None if any(out) else ValueError("no_results")
+        # as retrieve() (pipeline.py:112-122): "no_results" only when the store's result container itself is falsy; a
+        # non-empty container whose hit lists hold nothing usable clears the error
+        self.last_error = None if results else ValueError("no_results")
         return out

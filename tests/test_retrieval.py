@@ -153,3 +153,35 @@ def test_retrieve_batch_equals_retrieve_per_question(monkeypatch):
             return emb._vec(t).tolist()
 
     assert Retriever(PlainEmb(), Plain(store)).retrieve_batch(qs) == single
+
+
+def test_batch_and_single_paths_share_one_error_protocol():
+    """retrieve() follows the reference (pipeline.py:112-122): `no_results` only when the store's result container is falsy; a
+    non-empty container whose hits hold nothing usable clears the error.  retrieve_batch must record the same."""
+    class HollowHit:
+        entity = None  # hit_to_document -> None
+
+    class Hollow:
+        def connect(self):
+            pass
+
+        def search(self, vector, top_k=10):
+            return [[HollowHit()]]
+
+        def search_batch(self, vectors, top_k=10):
+            return np.zeros((len(vectors), 1), np.float32), np.zeros((len(vectors), 1), np.int64)
+
+        def hits_for(self, dist, rows):
+            return [[HollowHit()] for _ in range(len(rows))]
+
+    r = Retriever(WordEmbedder(), Hollow())
+    assert r.retrieve("alpha") == [] and r.last_error is None
+    r.last_error = RuntimeError("stale")
+    assert r.retrieve_batch(["alpha", "beta"]) == [[], []] and r.last_error is None
+
+    class Nothing(Hollow):
+        def hits_for(self, dist, rows):
+            return []
+
+    r = Retriever(WordEmbedder(), Nothing())
+    assert r.retrieve_batch(["alpha"]) == [] and str(r.last_error) == "no_results"

@@ -1,4 +1,6 @@
 """CPU: the host tokenizer against transformers' BertTokenizer on a synthetic vocabulary, and the factory's dispatch."""
+import json
+
 import numpy as np
 import pytest
 
@@ -68,6 +70,21 @@ def test_native_tokenizer_reproduces_committed_berttokenizer_ids(golden, tmp_pat
         for i, w in enumerate(want):
             assert ids[i, : lens[i]].tolist() == w, (name, i, g["texts"][i][:40])
         nat.close()
+
+
+def test_python_tokenizer_reproduces_the_same_committed_ids(golden):
+    """The Python WordPieceTokenizer (taken when the vocabulary is handed over as a dict) must give the ids the C++ tokenizer and
+    BertTokenizer give: it used to lower-case with str.lower(), whose Greek final-sigma rule ("ΟΔΟΣ" -> "οδος") neither of them
+    applies, and to keep private-use code points they drop -- the same text got different ids depending on how the provider was built."""
+    g = json.loads((golden / "tokenizer_unicode.json").read_text())
+    vocab = {t: i for i, t in enumerate(g["vocab"])}
+    for key, lower in (("uncased_512", True), ("cased_512", False), ("uncased_16", True), ("cased_16", False)):
+        tk = WordPieceTokenizer(vocab, lowercase=lower)
+        limit = int(key.split("_")[1])
+        for text, want in zip(g["texts"], g["ids"][key]):
+            assert tk.encode(text, limit) == want, (key, text)
+    tk = WordPieceTokenizer({"[PAD]": 0, "[UNK]": 1, "[CLS]": 2, "[SEP]": 3, "οδοσ": 4, "οδος": 5})
+    assert tk.encode("ΟΔΟΣ") == [2, 4, 3]  # code point by code point: no final sigma
 
 
 def test_native_tokenizer_equals_berttokenizer_on_every_code_point(tmp_path):
