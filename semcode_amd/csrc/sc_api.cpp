@@ -620,7 +620,17 @@ static sc_status ensure_shadow8(sc_index* ix) {
 }
 
 static const int BATCH_CAP = 4096;        // survivors kept per query and phase
-static const int64_t PHASE0_ROWS = 256;   // first phase (every row of it survives, and selection is quadratic in the survivors); each next phase covers 4x more rows
+// first phase: every row of it survives (thresholds start at +inf), so it must stay well below BATCH_CAP; each next phase covers 4x
+// more rows.  256 rows when the selection was a quadratic rank sort; with the radix select and the two-pass epilogue of the dense
+// phases 2 048 saves two launches + selections per batch (10M rows: 9 -> 7 phases).  SC_PHASE0 overrides (A/B).
+static int64_t phase0_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("SC_PHASE0");
+        const long long x = e ? atoll(e) : 2048;
+        return (int64_t)(x >= 256 && x <= 2048 ? (x / 256) * 256 : 2048);
+    }();
+    return v;
+}
 
 static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
@@ -677,7 +687,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
     else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
-    int64_t r0 = 0, span = PHASE0_ROWS;
+    int64_t r0 = 0, span = phase0_rows();
     while (r0 < ix->n) {
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;

@@ -274,15 +274,17 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 #define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 6 * 256 * 4)
 // per-tile staging of the workgroup's 256 query thresholds / norms and the tile's 256 row norms (visible to everyone after
 // the main loop's barriers)
-template <bool I8 = false>
+// ROWS / QUERIES: which half of the staging a call does (the persistent kernel stages the query side only when its query tile
+// changes and feeds the row side from registers it loaded a tile earlier)
+template <bool I8 = false, bool ROWS = true, bool QUERIES = true>
 static __device__ __forceinline__ void coarse256_stage(const CoarseArgs& a, int64_t m0, int n0, char* smem, int tid) {
     float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
-    if (tid >= 256) {
+    if (ROWS && tid >= 256) {
         const int64_t row = m0 + (tid - 256);
         q_tf[768 + tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
         if (I8) q_tf[1280 + tid - 256] = row < a.row1 ? a.xscale[row] : 0.0f;
     }
-    if (tid < 256) {
+    if (QUERIES && tid < 256) {
         const int q = n0 + tid;
         q_tf[tid] = q < a.Q ? a.thr_fast[q] : -__builtin_inff();  // padding never passes (and does not loosen the lane's prefilter bound)
         q_tf[256 + tid] = q < a.Q ? a.thr[q] : -__builtin_inff();
@@ -973,16 +975,42 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
 #pragma unroll
     for (int h = 0; h < 8; ++h) hook.coop(h, h, va, vw);  // the first tile's first two K-tiles, in ring order from parity 0
     int par = 0, it = 0;
+    // Staging without a global round trip in front of every tile: the row side (|x|^2 and the int8 row scale of the tile's 256 rows,
+    // threads 256..511) is loaded one tile ahead into two registers and only WRITTEN to LDS here; the query side (thresholds, norms,
+    // scales of the 256 queries) is staged again only when the query tile changes -- a workgroup's tiles are one round (a
+    // multiple of the group of 8 row panels x all query tiles, at 1 024 queries and 256 CUs) apart, so it never does there.
+    float* q_cur = reinterpret_cast<float*>(smem + COARSE_QLDS);
+    float xn_next = 1.0f, xs_next = 0.0f;
+    if (tid >= 256) {
+        const int64_t row = m0 + (tid - 256);
+        xn_next = row < a.row1 ? a.xnorm[row] : 1.0f;
+        if (I8) xs_next = row < a.row1 ? a.xscale[row] : 0.0f;
+    }
+    int n0_even = -1, n0_odd = -1;  // query tile staged in either copy
 #pragma unroll 1
     for (;; ++it) {
         char* smem_q = smem + (it & 1) * COARSE_QLDS_BYTES;  // this tile's thresholds / norms (the other copy may still be read)
-        coarse256_stage<I8>(a, m0, n0, smem_q, tid);
+        q_cur = reinterpret_cast<float*>(smem_q + COARSE_QLDS);
+        if (tid >= 256) {
+            q_cur[768 + tid - 256] = xn_next;
+            if (I8) q_cur[1280 + tid - 256] = xs_next;
+        }
+        if (((it & 1) ? n0_odd : n0_even) != n0) {
+            coarse256_stage<I8, false, true>(a, m0, n0, smem_q, tid);
+            if (it & 1) n0_odd = n0;
+            else n0_even = n0;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int next = tile + per_round;
         const bool more = next < hi;
         int64_t m0n = m0;
         int n0n = n0;
         if (more) coarse256_coords(a, next, m0n, n0n);  // the last tile "prefetches" itself: the request counts of the loop stay what they are
+        if (more && tid >= 256) {  // the next tile's row side: in flight under this tile's main loop
+            const int64_t row = m0n + (tid - 256);
+            xn_next = row < a.row1 ? a.xnorm[row] : 1.0f;
+            if (I8) xs_next = row < a.row1 ? a.xscale[row] : 0.0f;
+        }
         hook.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Xb + m0n * a.ld), 0, -1, 0x00020000);
         hook.rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Qb + (size_t)n0n * a.ld), 0, -1, 0x00020000);
         f32x4 acc[4][8];

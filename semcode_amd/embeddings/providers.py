@@ -128,11 +128,8 @@ class MI355XEmbeddings:
         if isinstance(weights, (str, Path)) and str(weights).lower().endswith(".gguf"):
             gguf_path = Path(weights)
         if weights is None and not allow_synthetic:
-            raise ValueError("Set SEMCODE_MI355X_WEIGHTS_PATH (.safetensors or .npy blob) when using the mi355x embedding provider "
+            raise ValueError("Set SEMCODE_MI355X_WEIGHTS_PATH (.safetensors, .gguf or .npy blob; a .gguf under SEMCODE_EMBEDDING_LLAMACPP_MODEL_PATH is taken too) when using the mi355x embedding provider "
                              "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for random-init benchmark weights).")
-        if vocab is None and not allow_synthetic:
-            raise ValueError("Set SEMCODE_MI355X_VOCAB_PATH (vocab.txt of the model) when using the mi355x embedding provider "
-                             "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for the hash-tokenizer stand-in).")
         self._native = _native
         self._cfg = dict(_native.BERT_BASE)
         self._vocab_tmp = None
@@ -158,6 +155,9 @@ class MI355XEmbeddings:
                     self._vocab_tmp.close()
                     vocab = self._vocab_tmp.name
         self._cfg.update(cfg or {})
+        if vocab is None and not allow_synthetic:  # (a GGUF file brings its own vocabulary: checked after it was read)
+            raise ValueError("Set SEMCODE_MI355X_VOCAB_PATH (vocab.txt of the model) when using the mi355x embedding provider "
+                             "(or SEMCODE_MI355X_ALLOW_SYNTHETIC=1 for the hash-tokenizer stand-in).")
         self.max_tokens = min(self.max_tokens, self._cfg["max_pos"])
         self._fast_tokenizer: Any = None
         self._owns_runtime = False  # an explicit runtime is the caller's; the default one is shared with the vector store
