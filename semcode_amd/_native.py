@@ -466,7 +466,7 @@ class Comm:
 
 
 BERT_BASE = dict(vocab=30522, hidden=768, layers=12, heads=12, ffn=3072, max_pos=512, type_vocab=2, ln_eps=1e-12)
-SEQ_BUCKETS = (32, 64, 128, 256, 512)
+SEQ_BUCKETS = (32, 64, 128, 256, 512, 1024, 2048)  # > 512: position-free (ALiBi) encoders, or a position table that long
 
 
 class Encoder:

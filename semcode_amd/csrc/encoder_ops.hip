@@ -335,18 +335,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // that only 64 score registers are live (S = 256 runs 2 workgroups per CU, S = 512 no longer spills).
 // FULL = every key of the padded sequence is real (len == S): no per-tile guards or masks.
 // ALIBI: scores get the symmetric linear bias -slope_head * |query - key| (jina-bert-v2 style encoders, no position table).
+// The online-softmax state of one 32-row query block: running maximum, running denominator, unnormalised output.  A sequence
+// longer than the 512 keys whose K and V fit the LDS is attended segment by segment (attention_long_kernel): the state is
+// carried from one segment of keys to the next.
+struct AttnState {
+    float m_run, l_run;
+    f32x16 o0, o1;
+};
+static __device__ __forceinline__ void attn_state_init(AttnState& a) {
+    a.m_run = -3.0e38f;
+    a.l_run = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a.o0[r] = 0.f; a.o1[r] = 0.f; }
+}
+// One segment of keys (the KT tiles in Kl / Vl = keys key0 .. key0 + 32 KT of the sequence; len / nkt count inside the segment)
+// folded into the state.  first: the state is fresh (no rescale of O before the first group).
 template <int KT, bool FULL, bool ALIBI, int GKMAX = 4>
-static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, char* ostg,
-                                                        bf16_t* obase, int H, int len, int nkt, int lane, int qbase, float slope2) {
+static __device__ __forceinline__ void attention_qblock_core(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, int len, int nkt, int lane,
+                                                             int qbase, float slope2, AttnState& S_, bool first, int key0) {
     constexpr int GK = KT < GKMAX ? KT : GKMAX;   // key tiles per group
     constexpr int NG = (KT + GK - 1) / GK;
     const int l31 = lane & 31, hh = lane >> 5;
     const float sl2 = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
     const int tail = len & 31;                           // != 0: the last real key tile is partially masked
-    float m_run = -3.0e38f, l_run = 0.f;
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = S_.m_run, l_run = S_.l_run;
+    f32x16 o0 = S_.o0, o1 = S_.o1;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (!FULL && g * GK >= nkt) continue;  // wave-uniform: nothing real in this group
@@ -369,7 +382,7 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
                 if (ALIBI) {  // work in the exp2 domain from here on: v = s * sl2 - slope2 * |q - key|
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float dist = (float)(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh - (qbase + l31));
+                        const float dist = (float)(key0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh - (qbase + l31));
                         acc[r] = fmaf(acc[r], sl2, -slope2 * fabsf(dist));
                     }
                 }
@@ -413,7 +426,7 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
         sum += __shfl_xor(sum, 32, 64);
         l_run = fmaf(l_run, alpha, sum);
         m_run = mx;
-        if (g > 0) {  // rescale O: its rows are queries (r&3) + 8 (r>>2) + 4 hh, alpha lives on lane q -> exchange through LDS
+        if (g > 0 || !first) {  // rescale O: its rows are queries (r&3) + 8 (r>>2) + 4 hh, alpha lives on lane q -> exchange through LDS
             xch[l31] = alpha;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -458,8 +471,17 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
             }
         }
     }
-    // o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS 8 query rows
-    // at a time (1 KiB, wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
+    S_.m_run = m_run;
+    S_.l_run = l_run;
+    S_.o0 = o0;
+    S_.o1 = o1;
+}
+// o[r] = O[q = (r&3) + 8 (r>>2) + 4 hh][d = 32 dt + l31]: normalise by 1/l[q], stage as bf16 [q][d] in LDS 8 query rows
+// at a time (1 KiB, wave-private; LDS runs a wave's instructions in order), then leave as whole 128-byte rows.
+static __device__ __forceinline__ void attn_state_store(const AttnState& S_, float* xch, char* ostg, bf16_t* obase, int H, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float l_run = S_.l_run;
+    const f32x16 o0 = S_.o0, o1 = S_.o1;
     xch[l31] = 1.0f / l_run;
     bf16_t* og = reinterpret_cast<bf16_t*>(ostg);
 #pragma unroll
@@ -475,6 +497,15 @@ static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], c
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(ostg + ql * 128 + c8 * 16);
         *reinterpret_cast<bf16x8*>(obase + (size_t)(8 * g4 + ql) * H + c8 * 8) = v;
     }
+}
+
+template <int KT, bool FULL, bool ALIBI, int GKMAX = 4>
+static __device__ __forceinline__ void attention_qblock(const bf16x8 (&qf)[4], const char* Kl, const char* Vl, float* xch, char* ostg,
+                                                        bf16_t* obase, int H, int len, int nkt, int lane, int qbase, float slope2) {
+    AttnState st;
+    attn_state_init(st);
+    attention_qblock_core<KT, FULL, ALIBI, GKMAX>(qf, Kl, Vl, xch, len, nkt, lane, qbase, slope2, st, true, 0);
+    attn_state_store(st, xch, ostg, obase, H, lane);
 }
 
 // NW waves per workgroup (4, or 8 for S = 256: one query block per wave, two key-tile groups of 2 -> half the registers, so that
@@ -541,6 +572,67 @@ __global__ __launch_bounds__(NW * 64, (KT <= 8 ? 2 : 1)) void attention_kernel(c
             else attention_qblock<KT, false, ALIBI, GKMAX>(qf[i], Kl, Vl, xch, ostg, obase, H, len, nkt, lane, qb * 32, slope2);
         }
     }
+}
+
+// ---- sequences of 1 024 and 2 048 tokens (the reference's default chunker emits up to 200 lines / 6 000 characters per chunk --
+// src/semcode/chunking/tree_sitter_chunker.py:64-65 -- i.e. 1.5-2k word pieces; jina-embeddings-v2 is an 8k-context ALiBi
+// model).  K and V of 512 keys fill the LDS (128 KiB), so the keys are attended in SEGMENTS of 512: stage a segment, every wave
+// folds it into the online-softmax state of its ONE 32-row query block (AttnState, 34 registers), next segment.  A workgroup
+// takes 8 query blocks (256 queries) of one (chunk, head); the S / 256 workgroups of a (chunk, head) each stage all its keys
+// (from L2 after the first).  Same arithmetic per (query, key) as attention_kernel: a sequence of <= 512 real tokens padded to
+// 1 024 gives the bits the S = 512 kernel gives.
+template <bool ALIBI>
+__global__ __launch_bounds__(512, 1) void attention_long_kernel(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ lens, int S, int H,
+                                                                const float* __restrict__ slopes, bf16_t* __restrict__ ctx, int blocked) {
+    constexpr int KT = 16, NW = 8, SEG = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + SEG * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* xch = reinterpret_cast<float*>(smem + 2 * SEG * 128) + w * 32;
+    char* ostg = smem + 2 * SEG * 128 + NW * 128 + w * 1024;
+    const int head = blockIdx.x, b = blockIdx.y, qb = (int)blockIdx.z * NW + w;  // this wave's 32-row query block
+    const int ld = blocked ? 64 : 3 * H;
+    const size_t T = (size_t)blocked, nh = (size_t)(H >> 6);
+    const bf16_t* base = blocked ? qkv + ((size_t)head * T + (size_t)b * S) * 64 : qkv + (size_t)b * S * ld + head * 64;
+    const size_t koff = blocked ? nh * T * 64 : (size_t)H, voff = 2 * koff;
+    int len = lens[b];
+    len = len < 1 ? 1 : (len > S ? S : len);
+    len = __builtin_amdgcn_readfirstlane(len);
+    const int l31 = lane & 31, hh = lane >> 5;
+    bf16x8 qf[4];
+    {
+        const bf16_t* qrow = base + (size_t)(qb * 32 + l31) * ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks + 8 * hh);
+    }
+    AttnState st;
+    attn_state_init(st);
+    const float slope2 = ALIBI ? slopes[head] * 1.44269504088896340736f : 0.f;
+    const int nseg = (len + SEG - 1) / SEG;
+#pragma unroll 1
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int key0 = seg * SEG;
+        const int slen = len - key0 < SEG ? len - key0 : SEG;  // real keys in this segment
+        const int nkt = (slen + 31) >> 5;
+        if (seg) __syncthreads();  // every wave is done with the previous segment's K / V
+        for (int piece = w; piece < nkt * 4; piece += NW) {
+            const int p = piece * 64 + lane;
+            const int r = p >> 3, ck = (p & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)(key0 + r) * ld + koff + ck * 8), (lds_vptr)(Kl + piece * 1024), 16, 0, 0);
+        }
+        for (int piece = w; piece < nkt * 4; piece += NW) {
+            const int p = piece * 64 + lane;
+            const int r = p >> 3, cv = (p & 7) ^ (((r >> 1) & 1) << 2);
+            __builtin_amdgcn_global_load_lds((gbl_vptr)(base + (size_t)(key0 + r) * ld + voff + cv * 8), (lds_vptr)(Vl + piece * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nkt == KT && (slen & 31) == 0) attention_qblock_core<KT, true, ALIBI, 4>(qf, Kl, Vl, xch, slen, nkt, lane, qb * 32, slope2, st, seg == 0, key0);
+        else attention_qblock_core<KT, false, ALIBI, 4>(qf, Kl, Vl, xch, slen, nkt, lane, qb * 32, slope2, st, seg == 0, key0);
+    }
+    attn_state_store(st, xch, ostg, ctx + (size_t)(b * S + qb * 32) * H + head * 64, H, lane);
 }
 
 // ------------------------------------------------------------------ masked mean pooling
@@ -623,7 +715,7 @@ static void launch_attn(const void* qkv, const int32_t* lens, int B, int H, cons
         hipLaunchKernelGGL((attention_kernel<KT, ALIBI, 4>), grid, dim3(256), (size_t)KT * 32 * 256 + 4 * 1152, s, (const bf16_t*)qkv, lens, H, slopes, (bf16_t*)ctx, blocked);
 }
 bool sc_attention_supported(int S, int H, int heads) {
-    return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512);
+    return heads > 0 && H == heads * 64 && (S == 32 || S == 64 || S == 128 || S == 256 || S == 512 || S == 1024 || S == 2048);
 }
 // slopes: NULL = plain attention; else [heads] ALiBi slopes (device)
 void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int H, const float* slopes, void* ctx, hipStream_t s, int blocked) {
@@ -632,6 +724,18 @@ void sc_launch_attention(const void* qkv, const int32_t* lens, int B, int S, int
         if (slopes) launch_attn<KK, true>(qkv, lens, B, H, slopes, ctx, blocked, s); \
         else launch_attn<KK, false>(qkv, lens, B, H, nullptr, ctx, blocked, s);   \
         break;
+    if (S > 512) {  // K / V streamed through the LDS in segments of 512 keys
+        static ScDeviceOnce once;
+        const int lds = 2 * 512 * 128 + 8 * 128 + 8 * 1024;
+        sc_device_once(once, [&] {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        });
+        const dim3 grid((unsigned)(H / 64), (unsigned)B, (unsigned)(S / 256));
+        if (slopes) hipLaunchKernelGGL(attention_long_kernel<true>, grid, dim3(512), (size_t)lds, s, (const bf16_t*)qkv, lens, S, H, slopes, (bf16_t*)ctx, blocked);
+        else hipLaunchKernelGGL(attention_long_kernel<false>, grid, dim3(512), (size_t)lds, s, (const bf16_t*)qkv, lens, S, H, (const float*)nullptr, (bf16_t*)ctx, blocked);
+        return;
+    }
     switch (S) {
         SC_ATTN_CASE(32, 1)
         SC_ATTN_CASE(64, 2)

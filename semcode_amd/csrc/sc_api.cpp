@@ -759,7 +759,10 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     // (search mode 2, "batched whenever supported", is the tests' switch: it keeps the int8 stage eligible at any size.)
     // ... and from 129 queries up: the int8 stage always runs 256-query tiles, and a batch of 32 spends 4.05 ms in them against the
     // 3.8 ms of the bf16 stage's 128-query tiles (profiles/r2p_bench.json.log sweep vs r1v)
-    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= ((int64_t)1 << 20) && Q > 128) || ix->search_mode == 2));
+    // (round 3: the persistent int8 kernel answers a 32-query batch in 3.1 ms where the bf16 stage's 128-query tiles take 3.9: the
+    // int8 stage now starts at 17 queries; SC_I8_MINQ restores any other limit for A/B runs)
+    static const int i8_minq = [] { const char* e = getenv("SC_I8_MINQ"); return e ? atoi(e) : 17; }();
+    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= ((int64_t)1 << 20) && Q >= i8_minq) || ix->search_mode == 2));
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
     ix->last_uncertified = 0;

@@ -463,7 +463,7 @@ static sc_status check_embed_args(sc_encoder* e, const void* ids, const void* le
     if (!e || !ids || !lens || !out) return sc_fail(SC_ERR_INVALID, "embed: NULL argument");
     if (B < 1 || B > 65536) return sc_fail(SC_ERR_INVALID, "embed: batch %d out of range", B);
     if (!sc_attention_supported(S, e->cfg.hidden, e->cfg.heads))
-        return sc_fail(SC_ERR_UNSUPPORTED, "embed: sequence length %d not in {32,64,128,256,512} (pad on the host)", S);
+        return sc_fail(SC_ERR_UNSUPPORTED, "embed: sequence length %d not in {32,64,128,256,512,1024,2048} (pad on the host)", S);
     if (S > e->cfg.max_pos && e->cfg.pos_type == 0) return sc_fail(SC_ERR_INVALID, "embed: sequence length %d exceeds max_pos %d", S, e->cfg.max_pos);
     return SC_OK;
 }
@@ -700,7 +700,7 @@ extern "C" sc_status sc_diag_gemm_i8(sc_runtime* rt, const int8_t* A, const int8
 extern "C" sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out) {
     if (!rt || !qkv || !lens || !out || B < 1) return sc_fail(SC_ERR_INVALID, "sc_diag_attention: bad argument");
     const int H = heads * 64;
-    if (!sc_attention_supported(S, H, heads)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_attention: S must be one of 32,64,128,256,512");
+    if (!sc_attention_supported(S, H, heads)) return sc_fail(SC_ERR_UNSUPPORTED, "sc_diag_attention: S must be one of 32,64,128,256,512,1024,2048");
     SC_HIP(hipSetDevice(rt->device));
     hipStream_t s = rt->stream;
     const int64_t tokens = (int64_t)B * S;

@@ -175,6 +175,22 @@ class MI355XEmbeddings:
             if isinstance(vocab, (str, Path)):  # the C++ tokenizer (ASCII fast path + full Unicode normalisation, multi-threaded)
                 self._fast_tokenizer = _native.NativeTokenizer(vocab)
         self.dimension = self._cfg["hidden"]
+        # Texts that reached max_tokens lost their tail.  The reference's default chunker emits up to 200 lines / 6 000 characters
+        # (tree_sitter_chunker.py:64-65: 1.5-2k word pieces) and only shrinks chunks for llamacpp / lmstudio (ingestion/manager.py:68-79),
+        # so with a 512-position BERT most real chunks are cut: counted here and logged (once per power of two), never silent.
+        self.truncated_texts = 0
+        self.total_texts = 0
+
+    def _note_truncation(self, lens: np.ndarray) -> None:
+        cut = int((np.asarray(lens) >= self.max_tokens).sum())
+        self.total_texts += int(len(lens))
+        if cut:
+            before = self.truncated_texts
+            self.truncated_texts += cut
+            if before == 0 or (self.truncated_texts.bit_length() != before.bit_length()):
+                log.warning("mi355x embeddings: %d of %d texts so far reached max_tokens=%d and were truncated (raise SEMCODE_MI355X_MAX_TOKENS up to "
+                            "the model's context -- 1024 / 2048 need a position-free (ALiBi) encoder -- or shrink the chunker's max_lines)",
+                            self.truncated_texts, self.total_texts, self.max_tokens)
 
     # ---- LangChain Embeddings surface (lists of Python floats)
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
@@ -196,7 +212,9 @@ class MI355XEmbeddings:
         """texts -> (ids [n, S] int32 padded to the smallest sequence bucket that fits, lens [n])."""
         if self._fast_tokenizer is None:
             toks = [self.tokenizer.encode(t, self.max_tokens) for t in texts]
-            return pack(toks, getattr(self.tokenizer, "pad_id", 0), self.max_tokens)
+            ids, lens = pack(toks, getattr(self.tokenizer, "pad_id", 0), self.max_tokens)
+            self._note_truncation(lens)
+            return ids, lens
         from .tokenizer import bucket_for
 
         smax = bucket_for(10 ** 9, self.max_tokens)
@@ -207,10 +225,11 @@ class MI355XEmbeddings:
             ids[i, len(t):] = self.tokenizer.pad_id
             lens[i] = len(t)
         S = bucket_for(int(lens.max()) if len(lens) else 1, self.max_tokens)
+        self._note_truncation(lens)
         return np.ascontiguousarray(ids[:, :S]), lens
 
     def embed_ids_array(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
-        """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512), lens [B] -> [B, hidden] f32."""
+        """Pre-tokenised input: ids [B, S] (S one of 32/64/128/256/512/1024/2048), lens [B] -> [B, hidden] f32."""
         return self._encoder.embed_ids(ids, lens)
 
     def embed_ids_into(self, store: Any, ids: np.ndarray, lens: np.ndarray, rows: np.ndarray, want_host: bool = False,

@@ -16,7 +16,7 @@ from typing import Iterable, List, Sequence
 
 import numpy as np
 
-SEQ_BUCKETS = (32, 64, 128, 256, 512)
+SEQ_BUCKETS = (32, 64, 128, 256, 512, 1024, 2048)
 
 
 def _is_punct(ch: str) -> bool:

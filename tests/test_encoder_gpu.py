@@ -76,14 +76,14 @@ def test_gemm_kernel(rt, epi, shape, splitk):
     assert err.max() <= scale * 2.0 ** -8 + 1e-3, (err.max(), scale, np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("S", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("S", [32, 64, 128, 256, 512, 1024, 2048])  # 1024 / 2048: keys streamed through the LDS in segments of 512
 def test_attention_kernel(rt, S):
-    B, heads = 3, 2
+    B, heads = 3 if S <= 512 else 4, 2
     H = heads * 64
     rng = np.random.default_rng(S)
     qkv = rng.standard_normal((B * S, 3 * H)).astype(np.float32)
     qkv[:, :H] *= 2.0  # sharper softmax
-    lens = np.array([S, max(1, S // 2 + 3), 1], np.int32)
+    lens = np.array([S, max(1, S // 2 + 3), 1] + ([S - 517] if S > 512 else []), np.int32)  # (S - 517: a ragged last segment)
     got = _native.diag_attention(rt, qkv, lens, B, S, heads)
     x = bf16_round(qkv).astype(np.float64).reshape(B, S, 3, heads, 64)
     q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
@@ -95,6 +95,22 @@ def test_attention_kernel(rt, S):
     err = np.abs(got - ref)
     assert err.max() <= 3e-2, (err.max(), np.unravel_index(err.argmax(), err.shape))  # P and O are rounded to bf16
     assert np.median(err) <= 3e-3
+
+
+def test_long_attention_equals_the_resident_kernel_on_short_sequences(rt):
+    """A sequence of <= 512 real tokens padded to 1 024 goes through the segmented kernel with ONE segment: same arithmetic per
+    (query, key), so the real rows carry the bits the S = 512 kernel writes."""
+    B, heads = 2, 2
+    H = heads * 64
+    rng = np.random.default_rng(5)
+    qkv = rng.standard_normal((B * 512, 3 * H)).astype(np.float32)
+    lens = np.array([512, 301], np.int32)
+    short = _native.diag_attention(rt, qkv, lens, B, 512, heads).reshape(B, 512, H)
+    pad = np.zeros((B, 1024, 3 * H), np.float32)
+    pad[:, :512] = qkv.reshape(B, 512, 3 * H)
+    long = _native.diag_attention(rt, pad.reshape(B * 1024, 3 * H), lens, B, 1024, heads).reshape(B, 1024, H)
+    for b in range(B):
+        assert np.array_equal(long[b, : lens[b]].view(np.uint32), short[b, : lens[b]].view(np.uint32))
 
 
 @pytest.fixture(scope="module")
@@ -275,6 +291,20 @@ def test_jina_v2_switches_match_restatement(rt, switches):
         ids = rng.integers(1, 400, size=(5, S)).astype(np.int32)
         lens = np.array([S, S // 2 + 1, 3, S - 1, 17], np.int32)
         check_pooled(enc.embed_ids(ids, lens), bo.forward(cfg, blob, ids, lens))
+    enc.close()
+
+
+def test_long_chunks_alibi_encoder_matches_restatement(rt):
+    """Chunks of 1 024 / 2 048 tokens (the reference's default chunker emits up to 200 lines / 6 000 characters,
+    tree_sitter_chunker.py:64-65; jina-embeddings-v2 is an 8k-context ALiBi model): the whole forward at S = 1024 and 2048 --
+    segmented attention with the ALiBi bias across segments -- against the numpy restatement (parity unpinned beyond it)."""
+    cfg = dict(bo.BERT_BASE, vocab=400, hidden=128, layers=2, heads=2, ffn=256, max_pos=64, alibi=True, geglu=True)
+    blob = bo.make_blob(cfg, 21, "test")
+    enc = _native.Encoder(rt, cfg, weights=blob)
+    rng = np.random.default_rng(9)
+    for S, lens in ((1024, [1024, 700, 513, 40]), (2048, [2048, 1500, 3])):
+        ids = rng.integers(1, 400, size=(len(lens), S)).astype(np.int32)
+        check_pooled(enc.embed_ids(ids, np.array(lens, np.int32)), bo.forward(cfg, blob, ids, np.array(lens, np.int32)))
     enc.close()
 
 
