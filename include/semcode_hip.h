@@ -197,7 +197,8 @@ sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t
 /* Process-wide test / tuning switches, by name (results stay identical; unknown names: SC_ERR_INVALID).  "coarse_workgroups": grid
  * of the persistent coarse-scan kernel (0 = one workgroup per CU), so that tests can make a few workgroups walk many tiles;
  * "coarse_persistent": 0 = one workgroup per tile instead; "gemm_pp": main loop of the 256-tile GEMMs (-1 default, 0 = one barrier
- * per K-tile, 2..5 = ping-pong with that many half-tiles in flight). */
+ * per K-tile, 2..5 = ping-pong with that many half-tiles in flight); "ivf_refresh_nomem": 1 = the re-layout of a trained IVF index
+ * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing). */
 sc_status sc_diag_set_option(const char* name, int32_t value);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
 sc_status sc_diag_attention(sc_runtime* rt, const float* qkv, const int32_t* lens, int32_t B, int32_t S, int32_t heads, float* out);

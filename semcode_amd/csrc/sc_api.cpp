@@ -359,11 +359,11 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
     // appended rows go behind the lists at position == row id.  The translated positions are a temporary: synchronise
     // before it goes out of scope (upserts into a trained index are not asynchronous).
     std::vector<int64_t> pos;
+    const int64_t* row_ids = rows;  // the caller's row numbers (rows is redirected to stored positions below)
     if (ix->perm) {
         pos.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) {
             pos[(size_t)i] = sc_ivf_pos(ix, rows[i]);
-            if (rows[i] < ix->ivf_rows) ix->dirty_rows.push_back(rows[i]);
         }
         min_old = INT64_MAX;  // the shadow is indexed by stored position
         for (int64_t i = 0; i < n; ++i)
@@ -390,6 +390,15 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
             sc_launch_ingest_rows((const float*)ix->stage, drows, 0, m, ix->dim, ix->X, ix->ld, ix->xnorm, s);
             SC_HIP(hipGetLastError());
             SC_HIP(hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+        }
+    }
+    if (ix->perm && row_ids) {  // rows of the lists whose vectors changed: re-assigned at the next refresh (recorded once, after the write)
+        const size_t before = ix->dirty_rows.size();
+        for (int64_t i = 0; i < n; ++i)
+            if (row_ids[i] < ix->ivf_rows) ix->dirty_rows.push_back(row_ids[i]);
+        if (ix->dirty_rows.size() > before && ix->dirty_rows.size() > 1024) {
+            std::sort(ix->dirty_rows.begin(), ix->dirty_rows.end());
+            ix->dirty_rows.erase(std::unique(ix->dirty_rows.begin(), ix->dirty_rows.end()), ix->dirty_rows.end());
         }
     }
     ix->n = next;
@@ -783,6 +792,14 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
     {   // rows upserted since the IVF lists were built join their lists first (no k-means): the reported ids of a
         // list-major corpus go through ix->perm, which must cover every stored row
         sc_status rst = sc_ivf_refresh_locked(ix);
+        if (rst == SC_ERR_NOMEM && ix->perm) {
+            // The re-layout needs a second copy of the corpus (246 GB at 10M x 3072).  Without it the rows upserted since the build
+            // cannot join their lists -- but they can still be FOUND: extend the position -> row id map over the tail (positions
+            // == row ids there, 4 B per row) and answer exhaustively (exact results) until a refresh or a rebuild succeeds.
+            rst = sc_ivf_cover_tail_locked(ix);
+            if (rst) return rst;
+            return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);
+        }
         if (rst) return rst;
     }
     if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);

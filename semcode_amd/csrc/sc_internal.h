@@ -89,6 +89,7 @@ struct sc_index {
     // overwritten in place since are listed in dirty_rows (their list may have changed).  The next search first assigns the
     // pending + dirty rows to the EXISTING centroids and re-orders the corpus once (sc_ivf_refresh_locked): no k-means.
     int64_t ivf_rows = 0;
+    int64_t perm_rows = 0;                        // entries of `perm` (== ivf_rows unless sc_ivf_cover_tail_locked extended it)
     std::vector<int64_t> dirty_rows;
     void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
     int last_probed_lists = 0;
@@ -110,6 +111,7 @@ bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, b
 sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
 void sc_ivf_drop_lists_locked(sc_index* ix);    // drop lists without restoring the order (the rows are about to be discarded)
+sc_status sc_ivf_cover_tail_locked(sc_index* ix);  // extend perm over rows appended since the build (identity): exhaustive search only
 sc_status sc_ivf_refresh_locked(sc_index* ix);  // fold rows upserted since the lists were built into them (no k-means)
 // stored position of row `r` (trained layout installed: ix->perm != nullptr)
 static inline int64_t sc_ivf_pos(const sc_index* ix, int64_t r) { return r < ix->ivf_rows ? (int64_t)ix->inv_h[(size_t)r] : r; }

@@ -71,6 +71,7 @@ void sc_ivf_drop_lists_locked(sc_index* ix) {
     hipFree(ix->perm);
     hipFree(ix->list_off);
     ix->perm = nullptr;
+    ix->perm_rows = 0;
     ix->list_off = nullptr;
     ix->inv_h.clear();
     ix->list_off_h.clear();
@@ -153,6 +154,7 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<i
     hipFree(ix->perm);
     hipFree(ix->list_off);
     ix->perm = d_perm.take<uint32_t>();
+    ix->perm_rows = 0;
     ix->list_off = d_off.take<int64_t>();
     ix->inv_h.swap(inv);
     ix->list_off_h.swap(off);
@@ -169,8 +171,30 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<i
 // Incremental upsert: rows appended or overwritten since the lists were built are assigned to the EXISTING centroids and the
 // corpus is re-ordered once (one pass over the corpus, no k-means).  The result is exactly what sc_index_assign_lists would
 // build from scratch for these centroids.  Called at the start of every search; caller holds ix->mu.
+static int g_ivf_refresh_nomem = 0;  // sc_diag_set_option("ivf_refresh_nomem", 1): tests of the fallback below
+void sc_ivf_set_refresh_nomem(int v) { g_ivf_refresh_nomem = v; }
+
+sc_status sc_ivf_cover_tail_locked(sc_index* ix) {
+    if (!ix->perm) return SC_OK;
+    const int64_t have = ix->perm_rows > 0 ? ix->perm_rows : ix->ivf_rows;
+    if (have >= ix->n) return SC_OK;
+    hipStream_t s = ix->rt->stream;
+    Dev d_new;
+    if (d_new.alloc((size_t)ix->n * 4) != hipSuccess) return sc_fail(SC_ERR_NOMEM, "ivf: hipMalloc of the extended row map failed");
+    SC_HIP(hipMemcpyAsync(d_new.p, ix->perm, (size_t)have * 4, hipMemcpyDeviceToDevice, s));
+    std::vector<uint32_t> tail((size_t)(ix->n - have));
+    for (int64_t r = have; r < ix->n; ++r) tail[(size_t)(r - have)] = (uint32_t)r;
+    SC_HIP(hipMemcpyAsync((uint32_t*)d_new.p + have, tail.data(), tail.size() * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipStreamSynchronize(s));
+    hipFree(ix->perm);
+    ix->perm = d_new.take<uint32_t>();
+    ix->perm_rows = ix->n;
+    return SC_OK;
+}
+
 sc_status sc_ivf_refresh_locked(sc_index* ix) {
     if (!ix->perm || !ix->quant || (ix->ivf_rows == ix->n && ix->dirty_rows.empty())) return SC_OK;
+    if (g_ivf_refresh_nomem) return sc_fail(SC_ERR_NOMEM, "ivf refresh: out of device memory (forced by sc_diag_set_option)");
     hipStream_t s = ix->rt->stream;
     std::vector<int64_t> rows(ix->dirty_rows);
     std::sort(rows.begin(), rows.end());

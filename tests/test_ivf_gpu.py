@@ -339,3 +339,38 @@ def test_gpu_build_matches_committed_build(rt, golden, metric):
         dist, rows = ix.search(d["Q"], k=10, nprobe=4)
         assert np.array_equal(rows, g[f"{metric}_rows"]) and np.array_equal(bits(dist), bits(g[f"{metric}_dist"])), mode
     ix.close()
+
+
+def test_search_survives_a_refresh_that_cannot_get_its_memory(rt):
+    """Upserts into a trained index are folded into the lists by a re-layout that needs a second copy of the corpus.  When that
+    allocation fails the search used to fail with it (and the store's Retriever then returned [] silently): now the rows upserted
+    since the build are covered by the position -> row id map and the query is answered exhaustively -- exact results, appended and
+    replaced rows included -- until a refresh succeeds again."""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((6000, 64)).astype(np.float32)
+    ix = _native.Index(rt, 64, metric="L2", kind="IVF_FLAT", nlist=16)
+    ix.add(X)
+    ix.train(niter=4)
+    extra = rng.standard_normal((300, 64)).astype(np.float32)
+    repl_rows = np.array([5, 999, 4321], np.int64)
+    repl = rng.standard_normal((3, 64)).astype(np.float32)
+    _native.diag_set_option("ivf_refresh_nomem", 1)
+    try:
+        ix.add(extra)
+        ix.overwrite(repl, repl_rows)
+        full = np.concatenate([X, extra])
+        full[repl_rows] = repl
+        Q = np.concatenate([extra[:5], repl, rng.standard_normal((4, 64)).astype(np.float32)])
+        for q in (Q, Q[:1]):
+            d, r = ix.search(q, k=8, nprobe=4)
+            od, orow = orc.search(full, q, 8, "L2")
+            assert np.array_equal(r, orow) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+        assert r[0, 0] == 6000  # an appended row is found
+    finally:
+        _native.diag_set_option("ivf_refresh_nomem", 0)
+    # memory is back: the next search folds the rows into their lists and probes again
+    d, r = ix.search(Q, k=8, nprobe=16)
+    od, orow = orc.search(full, Q, 8, "L2")
+    assert np.array_equal(r, orow) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+    assert ix.last_search_stats()["path"] in ("ivf", "ivf_listmajor", "exact", "batched")
+    ix.close()
