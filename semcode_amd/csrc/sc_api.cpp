@@ -681,6 +681,9 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
                  o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8);
+    // per-wave hit lists of the narrow int8 kernel (batches of <= 64 queries): 2048 lists x 1024 entries of 16 B
+    const size_t hit_bytes = (i8 && Q <= 64) ? (size_t)2048 * (4 + 1024 * 16) + 256 : 0;
+    const size_t o_hits = carve(hit_bytes ? hit_bytes : 16);
     // the fallback sub-batch (depth 1) runs while the caller's scratch is no longer needed: one buffer serves both
     st = sc_grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
     if (st) return st;
@@ -704,7 +707,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         // a query keeps about KP of the r0 rows seen so far: a 256 x 256 tile of this phase about 65536 KP / r0 survivors -- above a few
         // hundred the two-pass epilogue (one list-slot atomic per query and tile instead of one per survivor)
         const bool dense = r0 < (int64_t)256 * KP;
-        if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, r0, r1, ld8, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale, dense);
+        if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, r0, r1, ld8, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale, dense, hit_bytes ? (void*)(b + o_hits) : nullptr, hit_bytes);
         else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, false, nullptr, nullptr, dense);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);

@@ -155,7 +155,8 @@ void sc_launch_scan_batched_init(float* thr, float* thr_fast, int qpad, uint64_t
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
                            int cap, hipStream_t s, bool i8 = false, const float* xscale = nullptr, const float* qscale = nullptr,
-                           bool dense = false);  // dense: most scores of this row range are expected to survive (loose thresholds)
+                           bool dense = false,  // dense: most scores of this row range are expected to survive (loose thresholds)
+                           void* hit_scratch = nullptr, size_t hit_bytes = 0);  // per-wave hit lists of the narrow kernel (batches of <= 64 queries)
 void sc_launch_scan_select(int metric, uint64_t* surv, unsigned* count, int cap, uint64_t* best, const float* qnorm, float* thr,
                            float* thr_fast, int* overflow, int Q, int kp, hipStream_t s);
 void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* best,

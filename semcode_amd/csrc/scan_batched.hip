@@ -1037,6 +1037,226 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's self-prefetch must not outlive the workgroup's LDS
 }
 
+// ---- narrow streaming form for small batches (17 .. 64 queries, int8 shadow) -----------------------------------------------
+// A 256 x 256 tile spends 6.1 us of MFMAs per 256 corpus rows whatever the batch holds; below ~100 queries the bound is not the
+// matrix pipe but the memory system: the 7.7 GB int8 shadow streams in 1.2 ms.  This kernel is shaped for that: a persistent
+// workgroup (8 waves) walks row tiles of 256 rows x 64 query slots and sees the corpus as ONE stream of stages (tile, K-tile) --
+// 32 KiB of rows + 8 KiB of queries each -- through a three-deep LDS ring: two stages are always in flight, across tile
+// boundaries too, so neither the first bytes of a tile nor the threshold epilogue interrupts the stream.  Wave w multiplies rows
+// 32 w .. 32 w + 31 by all 64 slots (16 MFMAs per stage: the pipe idles, by design).  One barrier per stage.  Survivors (rare
+// in the phases this kernel serves) are appended to a per-wave list in global memory -- no atomics, nothing to wait for -- and a
+// small kernel scatters the lists into the per-query survivor lists afterwards.
+// 10M x 768, 32 queries: 2.6 ms through the 256-query tiles -> see profiles/r3*_q_sweep.log.
+#define C64_STAGE_A (256 * 128)
+#define C64_STAGE_W (64 * 128)
+#define C64_STAGE (C64_STAGE_A + C64_STAGE_W)
+#define C64_RING (3 * C64_STAGE)
+#define C64_LDS_BYTES (C64_RING + 3 * 512 * 4 + 4 * 64 * 4)
+template <int METRIC>
+__global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4_t* __restrict__ hitlist, unsigned* __restrict__ hitcount, int hitcap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld8 = a.ld * 2;  // bytes per int8 row (a.ld counts 2-byte elements)
+    const int nk = ld8 >> 7;   // stages per tile
+    const int64_t ntiles = (a.row1 - a.row0 + 255) >> 8;
+    const int64_t first = blockIdx.x;
+    if (first >= ntiles) {
+        if (tid < 8) hitcount[(size_t)blockIdx.x * 8 + tid] = 0;
+        return;
+    }
+    const int64_t mine = (ntiles - first + gridDim.x - 1) / gridDim.x, S = mine * nk;
+    // [3][xnorm 256 | xscale 256]: a tile's row side is requested two stages ahead, i.e. (one stage per tile, ld8 = 128) while the
+    // epilogue of the tile two before it is still reading its copy -- three copies
+    float* rowlds = reinterpret_cast<float*>(smem + C64_RING);
+    float* qlds = rowlds + 3 * 512;                             // thr_fast[64] | thr[64] | qnorm[64] | qscale[64]
+    if (tid < 64) {
+        const bool real = tid < a.Q;
+        qlds[tid] = real ? a.thr_fast[tid] : -__builtin_inff();
+        qlds[64 + tid] = real ? a.thr[tid] : -__builtin_inff();
+        qlds[128 + tid] = real ? a.qnorm[tid] : 1.0f;
+        qlds[192 + tid] = a.qscale[tid];  // padded to Qpad
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // per-lane source offsets: a piece = 8 rows x 128 B; the 16-byte chunk of row r at position pos comes from chunk pos ^ ((r >> 1) & 7)
+    uint32_t va[4], vw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (4 * w + i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        va[i] = (uint32_t)(r * ld8 + c * 16);
+    }
+    {
+        const int r = w * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        vw = (uint32_t)(r * ld8 + c * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.Qb, 0, -1, 0x00020000);
+    // row side: |x|^2 (waves 0-3) and the int8 row scale (waves 4-7), 64 rows per wave and tile; rows beyond row1 read as 0 (the
+    // descriptor ends at row1)
+    const float* rowsrc = w < 4 ? a.xnorm : a.xscale;
+    const uint32_t vrow = (uint32_t)(((w & 3) * 64 + lane) * 4);
+
+    int64_t t_i = first;  // issue side: tile and K-tile of the next stage to request
+    int kt_i = 0, j_i = 0;
+    auto issue = [&](int slot) {
+        char* dst = smem + slot * C64_STAGE;
+        const int64_t m0 = a.row0 + (t_i << 8);
+        if (kt_i == 0) {
+            const int64_t left = a.row1 - m0;
+            const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(rowsrc + m0), 0, (int)(left >= 256 ? 1024 : left > 0 ? left * 4 : 0), 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_vptr)(reinterpret_cast<char*>(rowlds) + ((j_i % 3) * 512 + (w >> 2) * 256 + (w & 3) * 64) * 4), 4, vrow, 0, 0, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Xb) + m0 * (int64_t)ld8), 0, -1, 0x00020000);
+        const uint32_t so = (uint32_t)kt_i * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_vptr)(dst + (4 * w + i) * 1024), 16, va[i], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_vptr)(dst + C64_STAGE_A + w * 1024), 16, vw, so, 0, 0);
+        if (++kt_i == nk) {
+            kt_i = 0;
+            t_i += gridDim.x;
+            ++j_i;
+        }
+    };
+    issue(0);
+    if (S > 1) issue(1);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw = (fr >> 1) & 7;
+    // fragment addresses inside a stage (k-step 0; k-step 1 = ^ 64): rows 32 w + 16 mi + fr of A, 16 ni + fr of W
+    const uint32_t a_rd = (uint32_t)((32 * w + fr) * 128 + ((fq ^ sw) << 4));
+    const uint32_t w_rd = (uint32_t)(C64_STAGE_A + fr * 128 + ((fq ^ sw) << 4));
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // this lane's 16 query slots: 16 ni + 4 fq + r
+    f32x4 tf[4], sq[4];
+    u32x4_t* hlist = hitlist + ((size_t)blockIdx.x * 8 + w) * (size_t)hitcap;
+    int hn = 0;
+    int64_t t_c = first;
+    int kt_c = 0, j_c = 0;
+#pragma unroll 1
+    for (int64_t s = 0; s < S; ++s) {
+        // stage s has landed (this wave's pieces); the stage behind it may fly (5 pieces, 6 when it opens a tile)
+        if (s + 1 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt_c + 1 == nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");  // ... and everyone's; every wave is done with stage s - 1, whose slot stage s + 2 takes
+        if (s + 2 < S) issue((int)((s + 2) % 3));
+        if (s == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                tf[ni] = *reinterpret_cast<const f32x4*>(qlds + ni * 16 + 4 * fq);
+                sq[ni] = *reinterpret_cast<const f32x4*>(qlds + 192 + ni * 16 + 4 * fq);
+            }
+        }
+        const char* st = smem + (int)(s % 3) * C64_STAGE;
+        bf16x8 af[2][2], wf[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi][ks] = *reinterpret_cast<const bf16x8*>(st + ((a_rd ^ (uint32_t)(ks << 6)) + mi * 2048));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni][ks] = *reinterpret_cast<const bf16x8*>(st + ((w_rd ^ (uint32_t)(ks << 6)) + ni * 2048));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = pp_mma<true>(wf[ni][ks], af[mi][ks], acc[ni][mi]);
+        if (kt_c + 1 < nk) {
+            ++kt_c;
+            continue;
+        }
+        // ---- the tile is complete: thresholds (the tests of coarse256_epilogue), survivors appended to this wave's list
+        const int64_t m0 = a.row0 + (t_c << 8);
+        const float* rs = rowlds + (j_c % 3) * 512;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int rl = 32 * w + 16 * mi + fr;
+            const int64_t row = m0 + rl;
+            const float xn = rs[rl], sx = rs[256 + rl];
+            const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
+            const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 t;
+                bool g = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float av = (float)__float_as_int(acc[ni][mi][r]) * ar;
+                    t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
+                    g |= t[r] <= tf[ni][r];
+                }
+                if (!__any(g && row < a.row1)) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool h = false;
+                    uint64_t key = 0;
+                    const int ql = 16 * ni + 4 * fq + r;
+                    if (row < a.row1 && t[r] <= tf[ni][r]) {
+                        const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
+                        const float sc = sc_score<METRIC>(dotv, xn, qlds[128 + ql]);
+                        const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
+                        if (v <= qlds[64 + ql]) {  // -inf for padded slots
+                            h = true;
+                            key = sc_make_key<METRIC>(sc, (uint32_t)row);
+                        }
+                    }
+                    const uint64_t m = __ballot(h);
+                    if (m) {
+                        const int off = hn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (h) {
+                            if (off < hitcap) {
+                                hlist[off] = u32x4_t{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)ql, 0u};
+                            } else {  // list full: allocate the slot here
+                                const unsigned pos = atomicAdd(a.count + ql, 1u);
+                                if (pos < (unsigned)a.cap) a.surv[(size_t)ql * a.cap + pos] = key;
+                            }
+                        }
+                        hn += (int)__popcll(m);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        hn = __builtin_amdgcn_readfirstlane(hn);
+        kt_c = 0;
+        t_c += gridDim.x;
+        ++j_c;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) hitcount[(size_t)blockIdx.x * 8 + w] = (unsigned)(hn < hitcap ? hn : hitcap);
+}
+
+// the per-wave hit lists of scan_coarse64s_kernel -> the per-query survivor lists (one wave per list)
+__global__ __launch_bounds__(64) void scan_hits_scatter_kernel(const u32x4_t* __restrict__ hitlist, const unsigned* __restrict__ hitcount, int hitcap,
+                                                               unsigned* __restrict__ count, uint64_t* __restrict__ surv, int cap) {
+    const unsigned n = hitcount[blockIdx.x];
+    const u32x4_t* l = hitlist + (size_t)blockIdx.x * (size_t)hitcap;
+    for (unsigned i = threadIdx.x; i < n; i += 64) {
+        const u32x4_t e = l[i];
+        const unsigned pos = atomicAdd(count + e[2], 1u);
+        if (pos < (unsigned)cap) surv[(size_t)e[2] * cap + pos] = ((uint64_t)e[1] << 32) | e[0];
+    }
+}
+
+template <int METRIC>
+static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scratch, size_t hit_bytes) {
+    static ScDeviceOnce once;
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
+    const int64_t ntiles = (a.row1 - a.row0 + 255) >> 8;
+    const int cus = sc_device_cus();
+    const int wgs = (int)std::min<int64_t>(ntiles, g_coarse_wgs > 0 ? g_coarse_wgs : cus);
+    const size_t lists = (size_t)wgs * 8, off = (lists * 4 + 255) & ~(size_t)255;
+    unsigned* hitcount = (unsigned*)hit_scratch;
+    u32x4_t* hitlist = (u32x4_t*)((char*)hit_scratch + off);
+    const int hitcap = (int)std::min<size_t>((hit_bytes - off) / (lists * 16), (size_t)1 << 20);
+    hipLaunchKernelGGL(scan_coarse64s_kernel<METRIC>, dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap);
+    hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, a.count, a.surv, a.cap);
+}
+bool sc_scan_coarse64_supported(int Q, int ld8, size_t hit_bytes) { return Q >= 1 && Q <= 64 && ld8 >= 128 && (ld8 % 128) == 0 && hit_bytes >= (size_t)2048 * (4 + 64 * 16) + 256; }
+
 template <int METRIC, bool I8>
 static void launch_coarse256(const CoarseArgs& a, hipStream_t s, bool dense) {
     static const char* envd = getenv("SC_COARSE_DENSE");  // A/B: 0 = the sparse epilogue everywhere
@@ -1127,10 +1347,21 @@ static void coarse256_trace(CoarseArgs a, bool i8, hipStream_t s) {
 
 void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64_t row0, int64_t row1, int ld, const void* Qb,
                            const float* qnorm, int Q, int Qpad, const float* thr, const float* thr_fast, uint64_t* surv, unsigned* count,
-                           int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale, bool dense) {
+                           int cap, hipStream_t s, bool i8, const float* xscale, const float* qscale, bool dense, void* hit_scratch, size_t hit_bytes) {
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = i8 ? ld / 2 : ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
     a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap; a.xscale = xscale; a.qscale = qscale;
+    static const char* env64 = getenv("SC_COARSE64");  // A/B: 0 = small batches through the 256-query tiles
+    if (i8 && !dense && hit_scratch && (row0 % T_BM) == 0 && sc_scan_coarse64_supported(Q, ld, hit_bytes) && !(env64 && env64[0] == '0') && !getenv("SC_COARSE_TRACE") &&
+        !getenv("SC_COARSE_DBG")) {
+        a.qtiles = 1;
+        a.ntiles = (int)((row1 - row0 + T_BM - 1) / T_BM);
+        a.trace = nullptr;
+        if (metric == SC_METRIC_L2) launch_coarse64s<SC_METRIC_L2>(a, s, hit_scratch, hit_bytes);
+        else if (metric == SC_METRIC_COSINE) launch_coarse64s<SC_METRIC_COSINE>(a, s, hit_scratch, hit_bytes);
+        else launch_coarse64s<SC_METRIC_IP>(a, s, hit_scratch, hit_bytes);
+        return;
+    }
     if ((Qpad % T_BN) == 0 && (row0 % T_BM) == 0) {  // large batches: 256 x 256 tiles (corpus rows are padded to 256)
         a.qtiles = Qpad / T_BN;
         a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);

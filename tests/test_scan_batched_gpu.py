@@ -62,6 +62,32 @@ def test_persistent_coarse_kernel_walks_many_tiles_per_workgroup(rt, dim, metric
         ix.close()
 
 
+@pytest.mark.parametrize("dim,metric,nq", [(768, "L2", 17), (768, "IP", 40), (768, "COSINE", 64), (192, "L2", 33), (100, "L2", 64), (448, "IP", 20)])
+def test_small_batches_take_the_narrow_streaming_kernel(rt, dim, metric, nq):
+    """17 .. 64 queries on the int8 stage: the sparse phases (from 256 x 512 rows on) run scan_coarse64s_kernel -- 256 rows x 64
+    query slots per tile, the shadow as one stream of stages through a three-deep ring, survivors appended to per-wave lists and
+    scattered afterwards.  Several stage counts per tile (768 dims = 6, 448 = 4, 192 = 2, 100 = 1), a ragged last tile, few
+    workgroups walking many tiles; the 256-query tiles (SC_COARSE64=0 is the A/B switch) and the oracle give the same bits."""
+    n = 200_000 + 77
+    X = orc.synth(n, dim, seed=51)
+    Q = orc.synth(nq, dim, seed=52)
+    od, orow = orc.search(X, Q, 10, metric)
+    ix = _native.Index(rt, dim, metric=metric)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    ix.set_coarse_stage(8)
+    try:
+        for wgs in (0, 16):
+            _native.diag_set_option("coarse_workgroups", wgs)
+            d, r = ix.search(Q, k=10)
+            st = ix.last_search_stats()
+            assert st["path"] == "batched" and st["coarse_bits"] == 8
+            assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)), (wgs, st)
+    finally:
+        _native.diag_set_option("coarse_workgroups", 0)
+        ix.close()
+
+
 @pytest.mark.parametrize("n", [1, 100, 127, 128, 129, 1000, 5000])
 def test_batched_small_and_ragged(rt, n):
     rng = np.random.default_rng(n)
