@@ -359,8 +359,9 @@ class Index:
         _check(lib().sc_index_assign_lists(self.handle, c.ctypes.data_as(C.c_void_p), c.shape[0]))
 
     def set_search_mode(self, mode: str) -> None:
-        """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (see sc_index_set_search_mode)."""
-        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3, "ivf_listmajor": 4}[mode]))
+        """'auto' | 'exact' | 'batched' | 'ivf' (per-query probing) | 'ivf_listmajor' (exact f32 list-major probing) | 'ivf_coarse' (list-major probing
+        behind the int8 coarse stage; L2 only) -- see sc_index_set_search_mode."""
+        _check(lib().sc_index_set_search_mode(self.handle, {"auto": 0, "exact": 1, "batched": 2, "ivf": 3, "ivf_listmajor": 4, "ivf_coarse": 5}[mode]))
 
     def set_coarse_stage(self, bits: int) -> None:
         """First coarse stage of the batched path: 0 auto (int8, then bf16), 8 int8 only, 16 bf16 only (sc_index_set_coarse_stage)."""
@@ -372,7 +373,7 @@ class Index:
         path, unc, bits, handed = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
         _check(lib().sc_index_last_coarse_stats(self.handle, C.byref(bits), C.byref(handed)))
-        out = {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor"}[path.value], "uncertified": unc.value}
+        out = {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor", 5: "ivf_coarse"}[path.value], "uncertified": unc.value}
         if path.value == 2:
             out.update(coarse_bits=bits.value, handed_to_bf16=handed.value)
         return out

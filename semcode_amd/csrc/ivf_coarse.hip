@@ -1,0 +1,188 @@
+// ivf_coarse.hip -- data preparation for the int8 coarse stage of IVF_FLAT probing (L2): centred shadows and per-pair queries.
+//
+// Replaces (reference): the scan Milvus' IVF_FLAT runs over the probed lists behind MilvusVectorStore.search
+// (src/semcode/storage/milvus_store.py:135-148; index parameters :76-83).  List-major probing scores every (query, probed row)
+// pair exactly in f32 on the matrix cores -- 9.8e11 FLOP per 1 024-query batch at config 5, bound by the f32 MFMA rate and by
+// re-streaming popular lists (29 ms, profiles/r3a_bench.json.log).  A low-precision coarse pass in front of it (as on the
+// exhaustive path) fails on exactly the data an IVF index is built for: inside a tight cluster the Cauchy-Schwarz bound on the
+// quantisation error, which scales with |x| |q|, exceeds the gap between the k-th and the kp-th neighbour.
+//
+// L2 distances do not change when x and q are shifted by the same vector.  So every list is quantised RELATIVE TO ITS CENTROID:
+//     x' = x - c_list,  q' = q - c_list   (one q' per (query, probed list) pair),   |x - q|^2 = |x'|^2 + |q'|^2 - 2 <x', q'>
+// and the error of the int8 dot product scales with |x'| |q'| -- the spread of the cluster, not its distance from the origin.
+// The coarse score of a pair is turned into a LOWER bound of the exact distance by subtracting the pair's own error bound
+// eps(list, pair); rows whose lower bound cannot beat the query's threshold are dropped, the survivors are re-scored exactly from
+// the original f32 rows (canonical fmaf chain: the returned distances are those of the exact path), and the result is certified
+// when the k-th exact distance lies below the final threshold -- no unseen row of the probed lists can then be closer.
+//
+//   ivf_center_shadow_kernel : Xc8 [rows][ld8] int8 of x', per-row scale, |x'|^2, per-list maxima of the rounding residual and |x'|
+//   ivf_pair_query_kernel    : per slot (query, list): int8 q', scale, |q'|^2 - eps  (the lower-bound form of the query norm)
+//   ivf_slot_thr_kernel      : per slot thresholds from the per-query ones, before every phase
+#include "sc_common.h"
+
+// lists[nlist + 1] ascending: the list whose range holds stored position r
+static __device__ __forceinline__ int list_of_pos(const int64_t* __restrict__ list_off, int nlist, int64_t r) {
+    int lo = 0, hi = nlist;  // invariant: list_off[lo] <= r < list_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (list_off[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// one wave per stored row; list_stats[list] = {bits of max |x' - s q|^2, bits of max |x'|^2}
+__global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __restrict__ X, int64_t rows, int ld, int ld8, const float* __restrict__ C, int ldc,
+                                                                 const int64_t* __restrict__ list_off, int nlist, int8_t* __restrict__ Xc8,
+                                                                 float* __restrict__ xcs, float* __restrict__ xcn, unsigned* __restrict__ list_stats) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const int l = list_of_pos(list_off, nlist, r);
+        const float* x = X + r * (int64_t)ld;
+        const float* c = C + (int64_t)l * ldc;
+        float m = 0.f, nn = 0.f;
+        for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0) - *reinterpret_cast<const f32x4*>(c + k0);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            m = fmaxf(m, __shfl_xor(m, off, 64));
+            nn += __shfl_xor(nn, off, 64);
+        }
+        const float sc = m > 0.f ? m * (1.0f / 127.0f) : 1.0f, inv = 1.0f / sc;
+        float res = 0.f;
+        int8_t* o = Xc8 + r * (int64_t)ld8;
+        for (int k0 = 16 * lane; k0 < ld8; k0 += 1024) {
+            u32x4 packed = {0u, 0u, 0u, 0u};
+            if (k0 < ld) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float qf = fminf(fmaxf(rintf(v[e] * inv), -127.0f), 127.0f);
+                        const float d = fmaf(-sc, qf, v[e]);
+                        res = fmaf(d, d, res);
+                        word |= ((uint32_t)(int)qf & 0xFFu) << (8 * e);
+                    }
+                    packed[j] = word;
+                }
+            }
+            *reinterpret_cast<u32x4*>(o + k0) = packed;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+        if (lane == 0) {
+            xcs[r] = sc;
+            xcn[r] = nn;
+            atomicMax(list_stats + 2 * l, __builtin_bit_cast(unsigned, res * 1.0001f));
+            atomicMax(list_stats + 2 * l + 1, __builtin_bit_cast(unsigned, nn * 1.0001f));
+        }
+    }
+}
+
+// One wave per slot.  slot_q / slot_l: the pair (-1 = padding slot: zeros, never passes).  Outputs: Qc8 [slot][ld8], slot_qs (scale),
+// slot_qnlb = |q'|^2 - eps: with it the coarse kernel's score  |x'|^2 + qnlb - 2 s_r s_q <xq, qq>  is a lower bound of |x - q|^2 up to
+// the f32 rounding of the exact path (which the certificate of the re-rank adds).  eps = 2 (|dx| |q'| + (|x'| + |dx|) |dq|) with the
+// list's maxima |dx| = max |x' - xq|, |x'| = max |x'| and the pair's |dq| = |q' - qq|, plus the rounding of the stored |x'|^2 / |q'|^2.
+__global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __restrict__ Qp, int ld, int ld8, const float* __restrict__ C, int ldc,
+                                                              const int32_t* __restrict__ slot_q, const int32_t* __restrict__ slot_l, int nslots,
+                                                              const unsigned* __restrict__ list_stats, int8_t* __restrict__ Qc8, float* __restrict__ slot_qs,
+                                                              float* __restrict__ slot_qnlb) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int slot = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= nslots) return;
+    const int q = slot_q[slot], l = slot_l[slot];
+    int8_t* o = Qc8 + (int64_t)slot * ld8;
+    if (q < 0) {
+        for (int k0 = 16 * lane; k0 < ld8; k0 += 1024) *reinterpret_cast<u32x4*>(o + k0) = u32x4{0u, 0u, 0u, 0u};
+        if (lane == 0) { slot_qs[slot] = 0.f; slot_qnlb[slot] = 0.f; }
+        return;
+    }
+    const float* x = Qp + (int64_t)q * ld;
+    const float* c = C + (int64_t)l * ldc;
+    float m = 0.f, nn = 0.f;
+    for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0) - *reinterpret_cast<const f32x4*>(c + k0);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, 64));
+        nn += __shfl_xor(nn, off, 64);
+    }
+    const float sc = m > 0.f ? m * (1.0f / 127.0f) : 1.0f, inv = 1.0f / sc;
+    float res = 0.f;
+    for (int k0 = 16 * lane; k0 < ld8; k0 += 1024) {
+        u32x4 packed = {0u, 0u, 0u, 0u};
+        if (k0 < ld) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
+                uint32_t word = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qf = fminf(fmaxf(rintf(v[e] * inv), -127.0f), 127.0f);
+                    const float d = fmaf(-sc, qf, v[e]);
+                    res = fmaf(d, d, res);
+                    word |= ((uint32_t)(int)qf & 0xFFu) << (8 * e);
+                }
+                packed[j] = word;
+            }
+        }
+        *reinterpret_cast<u32x4*>(o + k0) = packed;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
+    if (lane == 0) {
+        const float dx = sqrtf(__builtin_bit_cast(float, list_stats[2 * l])), xm = sqrtf(__builtin_bit_cast(float, list_stats[2 * l + 1]));
+        const float qn = sqrtf(nn * 1.0001f), dq = sqrtf(res * 1.0001f);
+        // dot-product error (Cauchy-Schwarz on the actual residuals) + the f32 rounding of the coarse score's own terms
+        float eps = 2.0f * (dx * qn + (xm + dx) * dq) + 4.0e-6f * (xm * xm + nn) + (float)ld * 2.4e-7f * (xm + dx) * qn;
+        eps = eps * 1.01f + 1e-6f;
+        slot_qs[slot] = sc;
+        slot_qnlb[slot] = nn - eps;
+    }
+}
+
+// per slot: thr / thr_fast of its query for this phase (scan_select_kernel's L2 formulas with the slot's lower-bound query norm)
+__global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __restrict__ slot_q, const float* __restrict__ slot_qnlb, const float* __restrict__ thr,
+                                                            int nslots, float* __restrict__ slot_thr, float* __restrict__ slot_tf) {
+    const int s = (int)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nslots) return;
+    const int q = slot_q[s];
+    float t = -__builtin_inff(), tf = -__builtin_inff();
+    if (q >= 0) {
+        t = thr[q];
+        const float qn = slot_qnlb[s];
+        tf = (t - qn) + (1e-3f * fabsf(t) + 1e-6f) + 1e-3f * fabsf(qn);  // superset of v <= t for the fast test v - qn <= tf
+        if (!(t < __builtin_inff())) tf = __builtin_inff();
+    }
+    slot_thr[s] = t;
+    slot_tf[s] = tf;
+}
+
+void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
+                                 float* xcs, float* xcn, unsigned* list_stats, hipStream_t s) {
+    if (rows <= 0) return;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(ivf_center_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, xcs, xcn, list_stats);
+}
+void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, hipStream_t s) {
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(ivf_pair_query_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8,
+                       slot_qs, slot_qnlb);
+}
+void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* thr, int nslots, float* slot_thr, float* slot_tf, hipStream_t s) {
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(ivf_slot_thr_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, slot_q, slot_qnlb, thr, nslots, slot_thr, slot_tf);
+}

@@ -236,6 +236,10 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->perm);
     hipFree(ix->list_off);
     hipFree(ix->ivf_scratch);
+    hipFree(ix->Xc8);
+    hipFree(ix->xcs);
+    hipFree(ix->list_stats);
+    hipFree(ix->ivfc_scratch);
     if (ix->quant) sc_index_destroy(ix->quant);
     sc_runtime* rt = ix->rt;
     delete ix;
@@ -405,6 +409,7 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
     if (!ix->perm) ix->trained = false;
     if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the shadows; appended rows get theirs lazily
     if (min_old < ix->shadow8_rows) ix->shadow8_rows = 0;
+    if (min_old != INT64_MAX) ix->shadowc_rows = 0;  // (the centred shadow of the IVF coarse stage is rebuilt with the lists)
     return SC_OK;
 }
 
@@ -806,6 +811,7 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         if (rst) return rst;
     }
     if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    if (sc_ivf_coarse_applicable(ix, Q, k, nprobe)) return sc_ivf_search_coarse_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
         return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);
@@ -815,8 +821,9 @@ sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int3
 }
 
 extern "C" sc_status sc_index_set_search_mode(sc_index* ix, int32_t mode) {
-    if (!ix || mode < 0 || mode > 4)
-        return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact), 2 (batched), 3 (ivf probe per query) or 4 (ivf probe list-major)");
+    if (!ix || mode < 0 || mode > 5)
+        return sc_fail(SC_ERR_INVALID, "sc_index_set_search_mode: mode must be 0 (auto), 1 (exact), 2 (batched), 3 (ivf probe per query), 4 (ivf probe list-major, exact f32) "
+                                       "or 5 (ivf probe list-major behind the int8 coarse stage)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->search_mode = mode;
     return SC_OK;

@@ -164,6 +164,16 @@ void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int l
                            int64_t row_base, const uint32_t* perm, float* out_dist, int64_t* out_rows, int* flags, hipStream_t s,
                            int kp, uint64_t* ekeys);
 
+// ivf_coarse.hip + scan_batched.hip: the int8 coarse stage of list-major IVF probing (L2)
+void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
+                                 float* xcs, float* xcn, unsigned* list_stats, hipStream_t s);
+void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, hipStream_t s);
+void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* thr, int nslots, float* slot_thr, float* slot_tf, hipStream_t s);
+void sc_launch_ivf_coarse(const void* Xc8, const float* xcn, const float* xcs, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
+                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, uint64_t* surv, unsigned* count, int cap,
+                          void* hit_scratch, size_t hit_bytes, hipStream_t s);
+
 // ivf.hip
 void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,
                         hipStream_t s);

@@ -92,6 +92,15 @@ struct sc_index {
     int64_t perm_rows = 0;                        // entries of `perm` (== ivf_rows unless sc_ivf_cover_tail_locked extended it)
     std::vector<int64_t> dirty_rows;
     void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
+    // int8 coarse stage of list-major probing (L2; ivf_coarse.hip): every list quantised relative to its centroid
+    void* Xc8 = nullptr;     size_t xc8_cap = 0;  // [ivf_rows padded to 256][ld8] int8 of x - c_list
+    float* xcs = nullptr;                         // [rows] scale,  xcn: [rows] |x - c_list|^2  (one allocation: xcs | xcn)
+    float* xcn = nullptr;    size_t xcsn_cap = 0;
+    unsigned* list_stats = nullptr;               // [nlist][2] bits of {max |x' - xq|^2, max |x'|^2} + [4] bits of max |x|^2 behind them
+    int64_t shadowc_rows = 0;                     // rows covered by the centred shadow (== ivf_rows when valid)
+    void* ivfc_scratch = nullptr; size_t ivfc_scratch_cap = 0;
+    bool ivfc_off = false;                        // the coarse stage left most of a batch uncertified on this index: probe exactly
+    int last_ivfc_uncertified = 0;
     int last_probed_lists = 0;
     int64_t last_unique_rows = 0, last_streamed_rows = 0;  // sc_index_last_probe_stats
     int last_groups = 0;
@@ -109,6 +118,8 @@ sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int
 sc_status sc_ivf_search_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, bool flat_is_batched);
 sc_status sc_ivf_search_listmajor_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
+bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe);
+sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
 void sc_ivf_drop_lists_locked(sc_index* ix);    // drop lists without restoring the order (the rows are about to be discarded)
 sc_status sc_ivf_cover_tail_locked(sc_index* ix);  // extend perm over rows appended since the build (identity): exhaustive search only

@@ -374,7 +374,7 @@ extern "C" sc_status sc_index_train(sc_index* ix, int32_t niter, uint64_t seed) 
 
 bool sc_ivf_applicable(const sc_index* ix, int Q, int nprobe) {
     if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant) return false;
-    if (nprobe < 1 || nprobe > 512 || ix->search_mode == 1 || ix->search_mode == 2 || ix->search_mode == 4) return false;
+    if (nprobe < 1 || nprobe > 512 || ix->search_mode == 1 || ix->search_mode == 2 || ix->search_mode == 4 || ix->search_mode == 5) return false;
     if (nprobe >= ix->nlist_trained) return false;  // probing every list = the exhaustive scan
     if (ix->search_mode == 3) return true;
     // one pass per query over nprobe/nlist of the corpus vs one exhaustive pass per 16 queries (or the
@@ -792,5 +792,226 @@ extern "C" sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* cent
     }
     if (list_sizes)
         for (int c = 0; c < ix->nlist_trained; ++c) list_sizes[c] = ix->list_off_h[(size_t)c + 1] - ix->list_off_h[(size_t)c];
+    return SC_OK;
+}
+
+// ---- list-major probing behind an int8 coarse stage (L2) ---------------------------------------------------------------------------
+// ivf_coarse.hip has the idea: every list quantised relative to its centroid, one centred int8 query per (query, probed list)
+// pair, coarse scores turned into lower bounds of the exact distance.  Here: the plan (pairs bucketed by list, groups of up to 64
+// query slots, one work item per 256-row tile of a list x group), two phases of the grouped streaming kernel
+// (scan_coarse64s_kernel<GROUPED>) with a selection of the 512 best lower bounds per query after each -- phase A: every query's
+// NEAREST list only (thresholds start at +inf: every row of it survives, and its 512th best is already a tight threshold because the
+// nearest cluster holds most of the neighbours); phase B: the other nprobe - 1 lists against those thresholds -- then the exact f32
+// re-rank of the candidates (canonical fmaf chain from the original rows: the distances of the exact paths) and the certificate:
+// k-th exact distance + the f32 rounding allowance < final threshold => no row of the probed lists that was dropped can be closer.
+// Uncertified queries (survivor-list overflow, too tight a gap) are probed again exactly (scan_listgemm / scan_exact kernels).
+// Results are therefore those of the exact list-major path, bit for bit.
+static const int IVFC_CAP = 8192;  // survivors per query and phase (a whole nearest list survives phase A)
+static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
+
+bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
+    static const bool env_off = [] { const char* e = getenv("SC_IVF_COARSE"); return e && e[0] == '0'; }();
+    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || !ix->perm || ix->metric != SC_METRIC_L2) return false;
+    if (nprobe < 2 || nprobe > 512 || nprobe >= ix->nlist_trained || k < 1 || k > sc_batched_kprime8() / 2) return false;
+    if (ix->search_mode == 5) return Q >= 1;
+    if (ix->search_mode != 0 || env_off || ix->ivfc_off) return false;
+    // auto: batches for which list-major probing would be chosen (every list wanted by several queries)
+    return Q >= 64 && (int64_t)Q * nprobe >= ix->nlist_trained && ix->n >= 100000;
+}
+
+static sc_status ivfc_ensure_shadow(sc_index* ix) {
+    if (ix->shadowc_rows == ix->ivf_rows && ix->Xc8) return SC_OK;
+    hipStream_t s = ix->rt->stream;
+    const int ld8 = ivfc_ld8(ix), nlist = ix->nlist_trained;
+    const int64_t rows = ix->ivf_rows, rows_pad = (rows + 255) / 256 * 256 + 256;  // (a list's last tile reads up to 255 rows beyond its end)
+    sc_status st = sc_grow(ix, &ix->Xc8, &ix->xc8_cap, (size_t)rows_pad * ld8);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->xcs, &ix->xcsn_cap, (size_t)rows_pad * 8);
+    if (st) return st;
+    ix->xcn = ix->xcs + rows_pad;
+    if (!ix->list_stats) SC_HIP(hipMalloc((void**)&ix->list_stats, ((size_t)ix->nlist * 2 + 4) * 4));
+    SC_HIP(hipMemsetAsync(ix->list_stats, 0, ((size_t)ix->nlist * 2 + 4) * 4, s));
+    SC_HIP(hipMemsetAsync((char*)ix->Xc8 + (size_t)rows * ld8, 0, (size_t)(rows_pad - rows) * ld8, s));
+    SC_HIP(hipMemsetAsync(ix->xcs + rows, 0, (size_t)(rows_pad - rows) * 4, s));
+    SC_HIP(hipMemsetAsync(ix->xcn + rows, 0, (size_t)(rows_pad - rows) * 4, s));
+    sc_launch_ivf_center_shadow(ix->X, rows, ix->ld, ld8, ix->quant->X, ix->quant->ld, ix->list_off, nlist, ix->Xc8, ix->xcs, ix->xcn, ix->list_stats, s);
+    sc_launch_norm_max(ix->xnorm, rows, ix->list_stats + (size_t)ix->nlist * 2, s);  // bits of max |x|^2: the re-rank's rounding allowance
+    SC_HIP(hipGetLastError());
+    ix->shadowc_rows = rows;
+    return SC_OK;
+}
+
+sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows) {
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    sc_index* qz = ix->quant;
+    const int nlist = ix->nlist_trained, ld = ix->ld, ld8 = ivfc_ld8(ix), KP = sc_batched_kprime8();
+    sc_status st = ivfc_ensure_shadow(ix);
+    if (st) return st;
+    const size_t npairs = (size_t)Q * nprobe;
+    // 1. coarse probe (the quantizer's own search) -> host
+    {
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_pd = carve(npairs * 4), o_pr = carve(npairs * 8);
+        st = sc_grow(ix, &ix->ivf_scratch, &ix->ivf_scratch_cap, off);
+        if (st) return st;
+        char* b = (char*)ix->ivf_scratch;
+        std::lock_guard<std::mutex> gq(qz->mu);
+        const sc_metric saved = qz->metric;
+        qz->metric = ix->metric;
+        st = sc_search_flat_locked(qz, q_dev, Q, nprobe, (float*)(b + o_pd), (int64_t*)(b + o_pr));
+        qz->metric = saved;
+        if (st) return st;
+    }
+    std::vector<int64_t> probes(npairs);
+    SC_HIP(hipMemcpyAsync(probes.data(), (char*)ix->ivf_scratch + ((npairs * 4 + 255) & ~(size_t)255), npairs * 8, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    // 2. plan.  Phase A = rank 0 of every query, phase B = the other ranks; per phase the pairs are bucketed by list (queries in
+    // ascending order: deterministic), cut into groups of 64 slots, and every group meets every 256-row tile of its list.
+    struct Item { long long row0; int rows; int slot_base; };
+    std::vector<int32_t> slot_q, slot_l;
+    std::vector<Item> items[2];
+    int64_t streamed_rows = 0, unique_rows = 0;
+    std::vector<char> touched((size_t)nlist, 0);
+    // phase A of a query = its nearest lists until they hold 2 KP rows (one list unless the lists are small): enough candidates
+    // for a finite threshold, which phase B needs -- at +inf every row of the other lists would survive
+    std::vector<int> ja((size_t)Q, 1);
+    for (int q = 0; q < Q; ++q) {
+        int64_t cum = 0;
+        int j = 0;
+        while (j < nprobe && cum < 2 * (int64_t)KP) {
+            const int64_t l = probes[(size_t)q * nprobe + j];
+            if (l >= 0 && l < nlist) cum += ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
+            ++j;
+        }
+        ja[(size_t)q] = j;
+    }
+    for (int ph = 0; ph < 2; ++ph) {
+        std::vector<int> start((size_t)nlist + 1, 0);
+        for (int q = 0; q < Q; ++q)
+            for (int j = ph == 0 ? 0 : ja[(size_t)q], j1 = ph == 0 ? ja[(size_t)q] : nprobe; j < j1; ++j) {
+                const int64_t l = probes[(size_t)q * nprobe + j];
+                if (l >= 0 && l < nlist) ++start[(size_t)l + 1];
+            }
+        for (int l = 0; l < nlist; ++l) start[(size_t)l + 1] += start[(size_t)l];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        std::vector<int32_t> qs((size_t)start[(size_t)nlist]);
+        for (int q = 0; q < Q; ++q)
+            for (int j = ph == 0 ? 0 : ja[(size_t)q], j1 = ph == 0 ? ja[(size_t)q] : nprobe; j < j1; ++j) {
+                const int64_t l = probes[(size_t)q * nprobe + j];
+                if (l >= 0 && l < nlist) qs[(size_t)fill[(size_t)l]++] = q;
+            }
+        for (int l = 0; l < nlist; ++l) {
+            const int m = start[(size_t)l + 1] - start[(size_t)l];
+            const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
+            if (m == 0 || end <= first) continue;
+            if (!touched[(size_t)l]) { touched[(size_t)l] = 1; unique_rows += end - first; }
+            for (int c = 0; c < m; c += 64) {
+                const int nq = std::min(64, m - c);
+                const int slot_base = (int)slot_q.size();
+                for (int sl = 0; sl < 64; ++sl) {
+                    slot_q.push_back(sl < nq ? qs[(size_t)start[(size_t)l] + c + sl] : -1);
+                    slot_l.push_back(sl < nq ? l : -1);
+                }
+                for (int64_t r0 = first; r0 < end; r0 += 256) items[ph].push_back({(long long)r0, (int)std::min<int64_t>(256, end - r0), slot_base});
+                streamed_rows += end - first;
+            }
+        }
+    }
+    const int nslots = (int)slot_q.size();
+    const size_t nitems = items[0].size() + items[1].size();
+    // 3. scratch: slot tables, per-pair queries, the batched path's per-query state, hit lists
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const int Qpad = (Q + 255) / 256 * 256;
+    const size_t o_sq = carve((size_t)nslots * 4), o_sl = carve((size_t)nslots * 4), o_qs = carve((size_t)nslots * 4), o_qn = carve((size_t)nslots * 4),
+                 o_st = carve((size_t)nslots * 4), o_stf = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
+                 o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
+                 o_qres = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8), o_ek = carve((size_t)Q * KP * 8), o_surv = carve((size_t)Q * IVFC_CAP * 8);
+    const size_t hit_bytes = (size_t)2048 * (4 + 8192 * 16) + 256;
+    const size_t o_hits = carve(hit_bytes);
+    st = sc_grow(ix, &ix->ivfc_scratch, &ix->ivfc_scratch_cap, off);
+    if (st) return st;
+    char* b = (char*)ix->ivfc_scratch;
+    int32_t *d_sq = (int32_t*)(b + o_sq), *d_sl = (int32_t*)(b + o_sl);
+    float *d_qs = (float*)(b + o_qs), *d_qn = (float*)(b + o_qn), *d_st = (float*)(b + o_st), *d_stf = (float*)(b + o_stf);
+    float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf), *qres = (float*)(b + o_qres);
+    unsigned* cnt = (unsigned*)(b + o_cnt);
+    int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
+    uint64_t *best = (uint64_t*)(b + o_best), *ekeys = (uint64_t*)(b + o_ek), *surv = (uint64_t*)(b + o_surv);
+    SC_HIP(hipMemcpyAsync(d_sq, slot_q.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(d_sl, slot_l.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, s));
+    if (!items[0].empty()) SC_HIP(hipMemcpyAsync(b + o_items, items[0].data(), items[0].size() * sizeof(Item), hipMemcpyHostToDevice, s));
+    if (!items[1].empty())
+        SC_HIP(hipMemcpyAsync(b + o_items + items[0].size() * sizeof(Item), items[1].data(), items[1].size() * sizeof(Item), hipMemcpyHostToDevice, s));
+    st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    if (st) return st;
+    sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
+    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, s);
+    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
+    SC_HIP(hipMemsetAsync(qres, 0, (size_t)Q * 4, s));
+    // 4. the two phases
+    hipEvent_t e0, e1;
+    size_t item0 = 0;
+    for (int ph = 0; ph < 2; ++ph) {
+        const int ni = (int)items[ph].size();
+        if (ni > 0) {
+            sc_launch_ivf_slot_thr(d_sq, d_qn, thr, nslots, d_st, d_stf, s);
+            sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+            sc_launch_ivf_coarse(ix->Xc8, ix->xcn, ix->xcs, ld8, b + o_qc, b + o_items + item0 * sizeof(Item), ni, d_stf, d_st, d_qn, d_qs, d_sq, surv, cnt, IVFC_CAP,
+                                 b + o_hits, hit_bytes, s);
+            sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+            sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+            sc_launch_scan_select(SC_METRIC_L2, surv, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
+            sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+        }
+        item0 += items[ph].size();
+    }
+    // 5. exact re-rank + certificate.  The thresholds are lower bounds already (the pair's error is inside the key), so the
+    // certificate only has to allow for the f32 rounding of the exact scores: bits = {max |x|^2, 0, 0}, |q - q~| = 0.
+    sc_launch_scan_rerank(SC_METRIC_L2, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->list_stats + (size_t)ix->nlist * 2, qres, ovf, Q, k, ix->row_base,
+                          ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
+    SC_HIP(hipGetLastError());
+    std::vector<int> hflags(Q);
+    SC_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)Q * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    std::vector<int> redo;
+    for (int i = 0; i < Q; ++i)
+        if (hflags[i]) redo.push_back(i);
+    const int R = (int)redo.size();
+    ix->last_ivfc_uncertified = R;
+    ix->last_uncertified = R;
+    if (ix->search_mode == 0 && Q >= 32 && R * 4 > Q) ix->ivfc_off = true;  // this index does not quantise well enough: later batches probe exactly
+    ix->last_probed_lists = nprobe;
+    ix->last_unique_rows = unique_rows;
+    ix->last_streamed_rows = streamed_rows;
+    ix->last_groups = (int)(nslots / 64);
+    if (R > 0) {  // probed again exactly: the sub-batch gets its own staging (queries + results)
+        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
+        st = sc_grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
+        if (st) return st;
+        float* fq = (float*)ix->fb;
+        float* fd = (float*)((char*)ix->fb + qb);
+        int64_t* frw = (int64_t*)((char*)ix->fb + qb + db);
+        for (int j = 0; j < R; ++j)
+            SC_HIP(hipMemcpyAsync(fq + (size_t)j * ix->dim, q_dev + (size_t)redo[j] * ix->dim, (size_t)ix->dim * 4, hipMemcpyDeviceToDevice, s));
+        const int saved_mode = ix->search_mode;
+        ix->search_mode = 4;
+        if (R >= 2) st = sc_ivf_search_listmajor_locked(ix, fq, R, k, nprobe, fd, frw);
+        else st = sc_ivf_search_locked(ix, fq, R, k, nprobe, fd, frw);
+        ix->search_mode = saved_mode;
+        if (st) return st;
+        for (int j = 0; j < R; ++j) {
+            SC_HIP(hipMemcpyAsync(out_dist + (size_t)redo[j] * k, fd + (size_t)j * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
+            SC_HIP(hipMemcpyAsync(out_rows + (size_t)redo[j] * k, frw + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
+        }
+        SC_HIP(hipStreamSynchronize(s));
+        ix->last_ivfc_uncertified = R;
+        ix->last_uncertified = R;
+    }
+    ix->last_path = 5;
     return SC_OK;
 }

@@ -1051,15 +1051,29 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
 #define C64_STAGE_W (64 * 128)
 #define C64_STAGE (C64_STAGE_A + C64_STAGE_W)
 #define C64_RING (3 * C64_STAGE)
-#define C64_LDS_BYTES (C64_RING + 3 * 512 * 4 + 4 * 64 * 4)
-template <int METRIC>
-__global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4_t* __restrict__ hitlist, unsigned* __restrict__ hitcount, int hitcap) {
+#define C64_LDS_BYTES (C64_RING + 3 * 512 * 4 + 3 * 512 * 4 + 4 * 64 * 4)
+// GROUPED (IVF_FLAT coarse stage, ivf_coarse.hip): a work item is one 256-row tile of a LIST PART against one group of up to 64
+// query SLOTS (the (query, list) pairs that probe the list): rows from the centred int8 shadow, slots from the per-pair centred
+// queries, thresholds / norms / scales / query ids per slot.  Same stream of stages, same tests; a hit names the slot's query.
+struct GroupItem {
+    long long row0;  // first stored position of the tile
+    int rows;        // valid rows (<= 256)
+    int slot_base;   // first of the group's 64 slots
+};
+struct GroupedArgs {
+    const GroupItem* items;
+    int nitems;
+    const float *slot_tf, *slot_thr, *slot_qn, *slot_qs;
+    const int32_t* slot_q;
+};
+template <int METRIC, bool GROUPED = false>
+__global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4_t* __restrict__ hitlist, unsigned* __restrict__ hitcount, int hitcap, GroupedArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld8 = a.ld * 2;  // bytes per int8 row (a.ld counts 2-byte elements)
     const int nk = ld8 >> 7;   // stages per tile
-    const int64_t ntiles = (a.row1 - a.row0 + 255) >> 8;
+    const int64_t ntiles = GROUPED ? (int64_t)ga.nitems : (a.row1 - a.row0 + 255) >> 8;
     const int64_t first = blockIdx.x;
     if (first >= ntiles) {
         if (tid < 8) hitcount[(size_t)blockIdx.x * 8 + tid] = 0;
@@ -1067,10 +1081,11 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
     }
     const int64_t mine = (ntiles - first + gridDim.x - 1) / gridDim.x, S = mine * nk;
     // [3][xnorm 256 | xscale 256]: a tile's row side is requested two stages ahead, i.e. (one stage per tile, ld8 = 128) while the
-    // epilogue of the tile two before it is still reading its copy -- three copies
+    // epilogue of the tile two before it is still reading its copy -- three copies; the slot side (GROUPED) likewise
     float* rowlds = reinterpret_cast<float*>(smem + C64_RING);
-    float* qlds = rowlds + 3 * 512;                             // thr_fast[64] | thr[64] | qnorm[64] | qscale[64]
-    if (tid < 64) {
+    float* slotlds = rowlds + 3 * 512;  // GROUPED: [3][8][64]: tf | thr | qn | qs | query id | (3 unused)
+    float* qlds = slotlds + 3 * 512;    // flat: thr_fast[64] | thr[64] | qnorm[64] | qscale[64]
+    if (!GROUPED && tid < 64) {
         const bool real = tid < a.Q;
         qlds[tid] = real ? a.thr_fast[tid] : -__builtin_inff();
         qlds[64 + tid] = real ? a.thr[tid] : -__builtin_inff();
@@ -1089,23 +1104,40 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
         const int r = w * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
         vw = (uint32_t)(r * ld8 + c * 16);
     }
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.Qb, 0, -1, 0x00020000);
-    // row side: |x|^2 (waves 0-3) and the int8 row scale (waves 4-7), 64 rows per wave and tile; rows beyond row1 read as 0 (the
-    // descriptor ends at row1)
+    // row side: |x|^2 (waves 0-3) and the int8 row scale (waves 4-7), 64 rows per wave and tile; rows beyond the tile's end read as 0
+    // (the descriptor ends there)
     const float* rowsrc = w < 4 ? a.xnorm : a.xscale;
     const uint32_t vrow = (uint32_t)(((w & 3) * 64 + lane) * 4);
+    const float* slotsrc = nullptr;  // GROUPED: wave w requests slot array w % 5 of the item (256 B)
+    if (GROUPED) {
+        const int k = w < 5 ? w : w - 5;
+        slotsrc = k == 0 ? ga.slot_tf : k == 1 ? ga.slot_thr : k == 2 ? ga.slot_qn : k == 3 ? ga.slot_qs : reinterpret_cast<const float*>(ga.slot_q);
+    }
 
     int64_t t_i = first;  // issue side: tile and K-tile of the next stage to request
     int kt_i = 0, j_i = 0;
+    int64_t m0_i = 0;
+    int rows_i = 256, sb_i = 0;
     auto issue = [&](int slot) {
         char* dst = smem + slot * C64_STAGE;
-        const int64_t m0 = a.row0 + (t_i << 8);
         if (kt_i == 0) {
-            const int64_t left = a.row1 - m0;
-            const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(rowsrc + m0), 0, (int)(left >= 256 ? 1024 : left > 0 ? left * 4 : 0), 0x00020000);
+            if (GROUPED) {
+                const GroupItem it = ga.items[t_i];
+                m0_i = it.row0;
+                rows_i = it.rows;
+                sb_i = it.slot_base;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slotsrc + sb_i), 0, 256, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(reinterpret_cast<char*>(slotlds) + ((j_i % 3) * 512 + w * 64) * 4), 4, (uint32_t)(lane * 4), 0, 0, 0);
+            } else {
+                m0_i = a.row0 + (t_i << 8);
+                const int64_t left = a.row1 - m0_i;
+                rows_i = (int)(left >= 256 ? 256 : left > 0 ? left : 0);
+            }
+            const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(rowsrc + m0_i), 0, rows_i * 4, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_vptr)(reinterpret_cast<char*>(rowlds) + ((j_i % 3) * 512 + (w >> 2) * 256 + (w & 3) * 64) * 4), 4, vrow, 0, 0, 0);
         }
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Xb) + m0 * (int64_t)ld8), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Xb) + m0_i * (int64_t)ld8), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Qb) + (int64_t)sb_i * ld8), 0, -1, 0x00020000);
         const uint32_t so = (uint32_t)kt_i * 128u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_vptr)(dst + (4 * w + i) * 1024), 16, va[i], so, 0, 0);
@@ -1127,27 +1159,19 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    // this lane's 16 query slots: 16 ni + 4 fq + r
-    f32x4 tf[4], sq[4];
     u32x4_t* hlist = hitlist + ((size_t)blockIdx.x * 8 + w) * (size_t)hitcap;
     int hn = 0;
     int64_t t_c = first;
     int kt_c = 0, j_c = 0;
+    constexpr int P0 = GROUPED ? 7 : 6;  // pieces of a stage that opens a tile: 5 + the row side (+ the slot side)
 #pragma unroll 1
     for (int64_t s = 0; s < S; ++s) {
-        // stage s has landed (this wave's pieces); the stage behind it may fly (5 pieces, 6 when it opens a tile)
+        // stage s has landed (this wave's pieces); the stage behind it may fly (5 pieces, P0 when it opens a tile)
         if (s + 1 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (kt_c + 1 == nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (kt_c + 1 == nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0) : "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");  // ... and everyone's; every wave is done with stage s - 1, whose slot stage s + 2 takes
         if (s + 2 < S) issue((int)((s + 2) % 3));
-        if (s == 0) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                tf[ni] = *reinterpret_cast<const f32x4*>(qlds + ni * 16 + 4 * fq);
-                sq[ni] = *reinterpret_cast<const f32x4*>(qlds + 192 + ni * 16 + 4 * fq);
-            }
-        }
         const char* st = smem + (int)(s % 3) * C64_STAGE;
         bf16x8 af[2][2], wf[4][2];
 #pragma unroll
@@ -1168,12 +1192,30 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
             continue;
         }
         // ---- the tile is complete: thresholds (the tests of coarse256_epilogue), survivors appended to this wave's list
-        const int64_t m0 = a.row0 + (t_c << 8);
+        int64_t m0;
+        int rows_c;
+        if (GROUPED) {
+            const GroupItem it = ga.items[t_c];
+            m0 = it.row0;
+            rows_c = it.rows;
+        } else {
+            m0 = a.row0 + (t_c << 8);
+            const int64_t left = a.row1 - m0;
+            rows_c = (int)(left >= 256 ? 256 : left);
+        }
         const float* rs = rowlds + (j_c % 3) * 512;
+        const float* sl = GROUPED ? slotlds + (j_c % 3) * 512 : qlds;  // tf | thr | qn | qs (| query id)
+        f32x4 tf[4], sq[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            tf[ni] = *reinterpret_cast<const f32x4*>(sl + ni * 16 + 4 * fq);
+            sq[ni] = *reinterpret_cast<const f32x4*>(sl + 192 + ni * 16 + 4 * fq);
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int rl = 32 * w + 16 * mi + fr;
             const int64_t row = m0 + rl;
+            const bool rowok = rl < rows_c;
             const float xn = rs[rl], sx = rs[256 + rl];
             const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
             const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
@@ -1187,17 +1229,17 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                     t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
                     g |= t[r] <= tf[ni][r];
                 }
-                if (!__any(g && row < a.row1)) continue;
+                if (!__any(g && rowok)) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     bool h = false;
                     uint64_t key = 0;
                     const int ql = 16 * ni + 4 * fq + r;
-                    if (row < a.row1 && t[r] <= tf[ni][r]) {
+                    if (rowok && t[r] <= tf[ni][r]) {
                         const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
-                        const float sc = sc_score<METRIC>(dotv, xn, qlds[128 + ql]);
+                        const float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
-                        if (v <= qlds[64 + ql]) {  // -inf for padded slots
+                        if (v <= sl[64 + ql]) {  // -inf for padded slots
                             h = true;
                             key = sc_make_key<METRIC>(sc, (uint32_t)row);
                         }
@@ -1206,11 +1248,12 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                     if (m) {
                         const int off = hn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         if (h) {
+                            const uint32_t qid = GROUPED ? (uint32_t)__float_as_int(sl[256 + ql]) : (uint32_t)ql;
                             if (off < hitcap) {
-                                hlist[off] = u32x4_t{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)ql, 0u};
+                                hlist[off] = u32x4_t{(uint32_t)key, (uint32_t)(key >> 32), qid, 0u};
                             } else {  // list full: allocate the slot here
-                                const unsigned pos = atomicAdd(a.count + ql, 1u);
-                                if (pos < (unsigned)a.cap) a.surv[(size_t)ql * a.cap + pos] = key;
+                                const unsigned pos = atomicAdd(a.count + qid, 1u);
+                                if (pos < (unsigned)a.cap) a.surv[(size_t)qid * a.cap + pos] = key;
                             }
                         }
                         hn += (int)__popcll(m);
@@ -1244,7 +1287,7 @@ __global__ __launch_bounds__(64) void scan_hits_scatter_kernel(const u32x4_t* __
 template <int METRIC>
 static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scratch, size_t hit_bytes) {
     static ScDeviceOnce once;
-    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<METRIC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<METRIC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
     const int64_t ntiles = (a.row1 - a.row0 + 255) >> 8;
     const int cus = sc_device_cus();
     const int wgs = (int)std::min<int64_t>(ntiles, g_coarse_wgs > 0 ? g_coarse_wgs : cus);
@@ -1252,8 +1295,30 @@ static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scrat
     unsigned* hitcount = (unsigned*)hit_scratch;
     u32x4_t* hitlist = (u32x4_t*)((char*)hit_scratch + off);
     const int hitcap = (int)std::min<size_t>((hit_bytes - off) / (lists * 16), (size_t)1 << 20);
-    hipLaunchKernelGGL(scan_coarse64s_kernel<METRIC>, dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap);
+    hipLaunchKernelGGL((scan_coarse64s_kernel<METRIC, false>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, GroupedArgs{});
     hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, a.count, a.surv, a.cap);
+}
+// IVF_FLAT coarse stage (L2): `nitems` work items {row0, rows, slot_base} over the centred int8 shadow Xc8 / per-pair queries Qc8; per-slot
+// thresholds etc.; hits go to the survivor lists of the slots' queries.  hit_scratch as for the flat form.
+void sc_launch_ivf_coarse(const void* Xc8, const float* xcn, const float* xcs, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
+                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, uint64_t* surv, unsigned* count, int cap,
+                          void* hit_scratch, size_t hit_bytes, hipStream_t s) {
+    if (nitems <= 0) return;
+    static ScDeviceOnce once;
+    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
+    CoarseArgs a;
+    a.Xb = (const bf16_t*)Xc8; a.xnorm = xcn; a.xscale = xcs; a.row0 = 0; a.row1 = 0; a.ld = ld8 / 2; a.Qb = (const bf16_t*)Qc8; a.qnorm = nullptr; a.Q = 0; a.qtiles = 1;
+    a.thr = nullptr; a.thr_fast = nullptr; a.surv = surv; a.count = count; a.cap = cap; a.ntiles = nitems; a.qscale = nullptr; a.trace = nullptr;
+    GroupedArgs ga;
+    ga.items = (const GroupItem*)items; ga.nitems = nitems; ga.slot_tf = slot_tf; ga.slot_thr = slot_thr; ga.slot_qn = slot_qn; ga.slot_qs = slot_qs; ga.slot_q = slot_q;
+    const int cus = sc_device_cus();
+    const int wgs = std::min(nitems, g_coarse_wgs > 0 ? g_coarse_wgs : cus);
+    const size_t lists = (size_t)wgs * 8, off = (lists * 4 + 255) & ~(size_t)255;
+    unsigned* hitcount = (unsigned*)hit_scratch;
+    u32x4_t* hitlist = (u32x4_t*)((char*)hit_scratch + off);
+    const int hitcap = (int)std::min<size_t>((hit_bytes - off) / (lists * 16), (size_t)1 << 20);
+    hipLaunchKernelGGL((scan_coarse64s_kernel<SC_METRIC_L2, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
+    hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, count, surv, cap);
 }
 bool sc_scan_coarse64_supported(int Q, int ld8, size_t hit_bytes) { return Q >= 1 && Q <= 64 && ld8 >= 128 && (ld8 % 128) == 0 && hit_bytes >= (size_t)2048 * (4 + 64 * 16) + 256; }
 

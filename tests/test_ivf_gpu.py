@@ -374,3 +374,53 @@ def test_search_survives_a_refresh_that_cannot_get_its_memory(rt):
     assert np.array_equal(r, orow) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
     assert ix.last_search_stats()["path"] in ("ivf", "ivf_listmajor", "exact", "batched")
     ix.close()
+
+
+@pytest.mark.parametrize("dim,n,ncl,nlist", [(96, 30_000, 25, 64), (768, 40_000, 40, 64), (2048, 12_000, 20, 32)])
+def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist):
+    """List-major probing behind the int8 coarse stage (lists quantised relative to their centroids, one centred query per (query,
+    list) pair, coarse scores as lower bounds, exact f32 re-rank, certificate; uncertified queries probed again exactly) returns
+    bit for bit what the exact list-major probe returns: tight and loose clusters, empty lists, lists longer than one row tile and
+    wanted by more queries than one group of 64 slots, k up to 64, few workgroups walking many work items."""
+    X, centers = clustered(n, dim, ncl, seed=41)
+    rng = np.random.default_rng(42)
+    ix = _native.Index(rt, dim, metric="L2", kind="IVF_FLAT", nlist=nlist)
+    ix.add(X)
+    ix.train(niter=5)
+    try:
+        for nq, k, nprobe, wgs in ((2, 10, 2, 0), (70, 1, 4, 0), (200, 10, 16, 8), (333, 64, 7, 0), (40, 5, nlist - 1, 24)):
+            Q = (centers[rng.integers(0, ncl, size=nq)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
+            ix.set_search_mode("ivf_listmajor")
+            d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
+            _native.diag_set_option("coarse_workgroups", wgs)
+            ix.set_search_mode("ivf_coarse")
+            d5, r5 = ix.search(Q, k=k, nprobe=nprobe)
+            st = ix.last_search_stats()
+            assert st["path"] == "ivf_coarse", st
+            assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (dim, nq, k, nprobe, st)
+            assert st["uncertified"] <= max(2, nq // 3), st  # the certificate holds for the bulk of a clustered batch
+    finally:
+        _native.diag_set_option("coarse_workgroups", 0)
+        ix.close()
+
+
+def test_coarse_stage_survives_upserts_and_near_duplicates(rt):
+    """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow; 700 near-duplicates of
+    one row (more than the 512 candidates a query keeps, gaps far below any int8 bound) leave their queries uncertified, and the exact probe answers them: same bits again."""
+    X, centers = clustered(20_000, 128, 30, seed=51)
+    rng = np.random.default_rng(52)
+    ix = _native.Index(rt, 128, metric="L2", kind="IVF_FLAT", nlist=32)
+    ix.add(X)
+    ix.train(niter=4)
+    dup = (X[123][None, :] + 1e-4 * rng.standard_normal((700, 128))).astype(np.float32)
+    ix.add(dup)
+    ix.overwrite(rng.standard_normal((2, 128)).astype(np.float32), np.array([7, 19_000], np.int64))
+    Q = np.concatenate([dup[:20], (centers[rng.integers(0, 30, size=80)] + 0.4 * rng.standard_normal((80, 128))).astype(np.float32)])
+    ix.set_search_mode("ivf_listmajor")
+    d4, r4 = ix.search(Q, k=10, nprobe=8)
+    ix.set_search_mode("ivf_coarse")
+    d5, r5 = ix.search(Q, k=10, nprobe=8)
+    st = ix.last_search_stats()
+    assert st["path"] == "ivf_coarse" and st["uncertified"] >= 1, st
+    assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5))
+    ix.close()
