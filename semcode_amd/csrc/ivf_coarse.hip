@@ -15,7 +15,7 @@
 // the original f32 rows (canonical fmaf chain: the returned distances are those of the exact path), and the result is certified
 // when the k-th exact distance lies below the final threshold -- no unseen row of the probed lists can then be closer.
 //
-//   ivf_center_shadow_kernel : Xc8 [rows][ld8] int8 of x', per-row scale, |x'|^2, per-list maxima of the rounding residual and |x'|
+//   ivf_center_shadow_kernel : Xc8 [rows][ld8] int8 of x', per row {|x'|^2, scale, 2 |dx|, 2 (|x'| + |dx|)}, per-list maxima of |dx|^2 and |x'|^2
 //   ivf_pair_query_kernel    : per slot (query, list): int8 q', scale, |q'|^2 - eps  (the lower-bound form of the query norm)
 //   ivf_slot_thr_kernel      : per slot thresholds from the per-query ones, before every phase
 #include "sc_common.h"
@@ -34,7 +34,7 @@ static __device__ __forceinline__ int list_of_pos(const int64_t* __restrict__ li
 // one wave per stored row; list_stats[list] = {bits of max |x' - s q|^2, bits of max |x'|^2}
 __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __restrict__ X, int64_t rows, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                                  const int64_t* __restrict__ list_off, int nlist, int8_t* __restrict__ Xc8,
-                                                                 float* __restrict__ xcs, float* __restrict__ xcn, unsigned* __restrict__ list_stats) {
+                                                                 f32x4* __restrict__ xrow, unsigned* __restrict__ list_stats) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) res += __shfl_xor(res, off, 64);
         if (lane == 0) {
-            xcs[r] = sc;
-            xcn[r] = nn;
+            // the row's record for the coarse kernel: |x'|^2, scale, and the two row factors of its error bound
+            //   eps(row, pair) = 2 |dx_r| |q'| + 2 (|x'_r| + |dx_r|) |dq|      (Cauchy-Schwarz on the actual rounding residuals)
+            const float dx = sqrtf(res * 1.0001f), xm = sqrtf(nn * 1.0001f);
+            xrow[r] = f32x4{nn, sc, 2.0f * dx, 2.0f * (xm + dx)};
             atomicMax(list_stats + 2 * l, __builtin_bit_cast(unsigned, res * 1.0001f));
             atomicMax(list_stats + 2 * l + 1, __builtin_bit_cast(unsigned, nn * 1.0001f));
         }
@@ -87,13 +89,15 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
 }
 
 // One wave per slot.  slot_q / slot_l: the pair (-1 = padding slot: zeros, never passes).  Outputs: Qc8 [slot][ld8], slot_qs (scale),
-// slot_qnlb = |q'|^2 - eps: with it the coarse kernel's score  |x'|^2 + qnlb - 2 s_r s_q <xq, qq>  is a lower bound of |x - q|^2 up to
-// the f32 rounding of the exact path (which the certificate of the re-rank adds).  eps = 2 (|dx| |q'| + (|x'| + |dx|) |dq|) with the
-// list's maxima |dx| = max |x' - xq|, |x'| = max |x'| and the pair's |dq| = |q' - qq|, plus the rounding of the stored |x'|^2 / |q'|^2.
+// slot_qnlb = |q'|^2 minus the f32 rounding allowance of the coarse score's own terms, slot_qb = |q'|, slot_qd = |q' - qq| (the pair
+// factors of the per-row error bound the kernel subtracts: score - 2 |dx_r| |q'| - 2 (|x'_r| + |dx_r|) |dq| is a lower bound of
+// |x - q|^2 up to the f32 rounding of the exact path, which the certificate of the re-rank adds), and slot_eps = that bound with the
+// LIST's maxima in place of the row's: the fast test of the kernel must pass whatever any row of the list could pass.
 __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __restrict__ Qp, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                               const int32_t* __restrict__ slot_q, const int32_t* __restrict__ slot_l, int nslots,
                                                               const unsigned* __restrict__ list_stats, int8_t* __restrict__ Qc8, float* __restrict__ slot_qs,
-                                                              float* __restrict__ slot_qnlb) {
+                                                              float* __restrict__ slot_qnlb, float* __restrict__ slot_qb, float* __restrict__ slot_qd,
+                                                              float* __restrict__ slot_eps) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int slot = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     int8_t* o = Qc8 + (int64_t)slot * ld8;
     if (q < 0) {
         for (int k0 = 16 * lane; k0 < ld8; k0 += 1024) *reinterpret_cast<u32x4*>(o + k0) = u32x4{0u, 0u, 0u, 0u};
-        if (lane == 0) { slot_qs[slot] = 0.f; slot_qnlb[slot] = 0.f; }
+        if (lane == 0) { slot_qs[slot] = 0.f; slot_qnlb[slot] = 0.f; slot_qb[slot] = 0.f; slot_qd[slot] = 0.f; slot_eps[slot] = 0.f; }
         return;
     }
     const float* x = Qp + (int64_t)q * ld;
@@ -144,17 +148,19 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     if (lane == 0) {
         const float dx = sqrtf(__builtin_bit_cast(float, list_stats[2 * l])), xm = sqrtf(__builtin_bit_cast(float, list_stats[2 * l + 1]));
         const float qn = sqrtf(nn * 1.0001f), dq = sqrtf(res * 1.0001f);
-        // dot-product error (Cauchy-Schwarz on the actual residuals) + the f32 rounding of the coarse score's own terms
-        float eps = 2.0f * (dx * qn + (xm + dx) * dq) + 4.0e-6f * (xm * xm + nn) + (float)ld * 2.4e-7f * (xm + dx) * qn;
-        eps = eps * 1.01f + 1e-6f;
+        // f32 rounding of the coarse score's own terms (stored norms, scaling of the integer dot): taken off the query norm
+        const float round_eps = (4.0e-6f * (xm * xm + nn) + (float)ld * 2.4e-7f * (xm + dx) * qn) * 1.01f + 1e-6f;
         slot_qs[slot] = sc;
-        slot_qnlb[slot] = nn - eps;
+        slot_qnlb[slot] = nn - round_eps;
+        slot_qb[slot] = qn * 1.01f;
+        slot_qd[slot] = dq * 1.01f;
+        slot_eps[slot] = (2.0f * (dx * qn + (xm + dx) * dq)) * 1.03f + 1e-6f;  // >= the kernel's row-wise bound for every row of the list
     }
 }
 
 // per slot: thr / thr_fast of its query for this phase (scan_select_kernel's L2 formulas with the slot's lower-bound query norm)
-__global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __restrict__ slot_q, const float* __restrict__ slot_qnlb, const float* __restrict__ thr,
-                                                            int nslots, float* __restrict__ slot_thr, float* __restrict__ slot_tf) {
+__global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __restrict__ slot_q, const float* __restrict__ slot_qnlb, const float* __restrict__ slot_eps,
+                                                            const float* __restrict__ thr, int nslots, float* __restrict__ slot_thr, float* __restrict__ slot_tf) {
     const int s = (int)blockIdx.x * 256 + threadIdx.x;
     if (s >= nslots) return;
     const int q = slot_q[s];
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __rest
     if (q >= 0) {
         t = thr[q];
         const float qn = slot_qnlb[s];
-        tf = (t - qn) + (1e-3f * fabsf(t) + 1e-6f) + 1e-3f * fabsf(qn);  // superset of v <= t for the fast test v - qn <= tf
+        // the fast test (score - qn <= tf) must pass whatever the precise one (score - row-wise bound <= t) can pass
+        tf = (t - qn) + slot_eps[s] + (1e-3f * fabsf(t) + 1e-6f) + 1e-3f * fabsf(qn);
         if (!(t < __builtin_inff())) tf = __builtin_inff();
     }
     slot_thr[s] = t;
@@ -170,19 +177,20 @@ __global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __rest
 }
 
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xcs, float* xcn, unsigned* list_stats, hipStream_t s) {
+                                 float* xrow, unsigned* list_stats, hipStream_t s) {
     if (rows <= 0) return;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(ivf_center_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, xcs, xcn, list_stats);
+    hipLaunchKernelGGL(ivf_center_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow, list_stats);
 }
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
-                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, hipStream_t s) {
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s) {
     if (nslots <= 0) return;
     hipLaunchKernelGGL(ivf_pair_query_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8,
-                       slot_qs, slot_qnlb);
+                       slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
 }
-void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* thr, int nslots, float* slot_thr, float* slot_tf, hipStream_t s) {
+void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
+                            hipStream_t s) {
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(ivf_slot_thr_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, slot_q, slot_qnlb, thr, nslots, slot_thr, slot_tf);
+    hipLaunchKernelGGL(ivf_slot_thr_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, slot_q, slot_qnlb, slot_eps, thr, nslots, slot_thr, slot_tf);
 }

@@ -147,3 +147,25 @@ void sc_launch_gather_rows(const float* src, int ld, int64_t first, int64_t n, i
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, ld, first, n, dim, dst);
 }
+
+// Rows of `words` 4-byte words moved by index: gather  dst[i] = src[idx[i]]  or scatter  dst[idx[i]] = src[i].  The sub-batches of
+// uncertified queries (and their results on the way back) used to travel as one hipMemcpyAsync per query: ~9 us each, 3.3 ms for the
+// 124 queries the IVF coarse stage hands back at config 5.
+__global__ __launch_bounds__(256) void copy_rows_indexed_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const int32_t* __restrict__ idx, int n,
+                                                                 int words, int scatter) {
+    const int64_t total = (int64_t)n * words;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / words;
+        const int c = (int)(i - r * words);
+        const int64_t o = (int64_t)idx[r] * words + c;
+        if (scatter) dst[o] = src[i];
+        else dst[i] = src[o];
+    }
+}
+void sc_launch_copy_rows_indexed(const void* src, void* dst, const int32_t* idx_dev, int n, size_t row_bytes, bool scatter, hipStream_t s) {
+    if (n <= 0 || row_bytes == 0) return;
+    const int words = (int)(row_bytes / 4);
+    int64_t blocks = ((int64_t)n * words + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(copy_rows_indexed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, idx_dev, n, words, scatter ? 1 : 0);
+}

@@ -747,21 +747,22 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         // the sub-batch gets its own staging (queries + results); nested stages each need one: fb for the first, fb2 for the second
         void** buf = depth == 0 ? &ix->fb : &ix->fb2;
         size_t* cap = depth == 0 ? &ix->fb_cap : &ix->fb2_cap;
-        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
-        st = sc_grow(ix, buf, cap, qb + db + (size_t)R * k * 8);
+        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255, rb = ((size_t)R * k * 8 + 255) & ~(size_t)255;
+        st = sc_grow(ix, buf, cap, qb + db + rb + (size_t)R * 4);
         if (st) return st;
         float* fq = (float*)*buf;
         float* fd = (float*)((char*)*buf + qb);
         int64_t* fr = (int64_t*)((char*)*buf + qb + db);
-        for (int j = 0; j < R; ++j)
-            SC_HIP(hipMemcpyAsync(fq + (size_t)j * ix->dim, q_dev + (size_t)redo[j] * ix->dim, (size_t)ix->dim * 4, hipMemcpyDeviceToDevice, s));
+        int32_t* fidx = (int32_t*)((char*)*buf + qb + db + rb);
+        // one gather and two scatters by query index (one hipMemcpyAsync per query cost ~9 us each)
+        SC_HIP(hipMemcpyAsync(fidx, redo.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+        sc_launch_copy_rows_indexed(q_dev, fq, fidx, R, (size_t)ix->dim * 4, false, s);
         if (to_bf16) st = search_batched_stage_locked(ix, fq, R, k, fd, fr, false, depth + 1, Q_top);
         else st = search_exact_locked(ix, fq, R, k, 0, fd, fr);
         if (st) return st;
-        for (int j = 0; j < R; ++j) {
-            SC_HIP(hipMemcpyAsync(out_dist + (size_t)redo[j] * k, fd + (size_t)j * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
-            SC_HIP(hipMemcpyAsync(out_rows + (size_t)redo[j] * k, fr + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
-        }
+        sc_launch_copy_rows_indexed(fd, out_dist, fidx, R, (size_t)k * 4, true, s);
+        sc_launch_copy_rows_indexed(fr, out_rows, fidx, R, (size_t)k * 8, true, s);
+        SC_HIP(hipStreamSynchronize(s));  // `redo` is on this stack frame
     }
     ix->last_path = 2;
     return SC_OK;

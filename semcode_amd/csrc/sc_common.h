@@ -104,6 +104,8 @@ void sc_launch_synth_clustered(float* out, int64_t rows, int dim, int ld, uint64
 void sc_launch_ingest_rows(const float* src, const int64_t* rows, int64_t first, int64_t n, int dim, float* dst, int ld,
                            float* xnorm, hipStream_t s);
 void sc_launch_gather_rows(const float* src, int ld, int64_t first, int64_t n, int dim, float* dst, hipStream_t s);
+// rows of row_bytes (a multiple of 4) by index: gather dst[i] = src[idx[i]], or scatter dst[idx[i]] = src[i]
+void sc_launch_copy_rows_indexed(const void* src, void* dst, const int32_t* idx_dev, int n, size_t row_bytes, bool scatter, hipStream_t s);
 
 struct ScanPlan {
     int qt;          // queries per group (<=16)
@@ -166,13 +168,14 @@ void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int l
 
 // ivf_coarse.hip + scan_batched.hip: the int8 coarse stage of list-major IVF probing (L2)
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xcs, float* xcn, unsigned* list_stats, hipStream_t s);
+                                 float* xrow, unsigned* list_stats, hipStream_t s);
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
-                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, hipStream_t s);
-void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* thr, int nslots, float* slot_thr, float* slot_tf, hipStream_t s);
-void sc_launch_ivf_coarse(const void* Xc8, const float* xcn, const float* xcs, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
-                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, uint64_t* surv, unsigned* count, int cap,
-                          void* hit_scratch, size_t hit_bytes, hipStream_t s);
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s);
+void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
+                            hipStream_t s);
+void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
+                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, const float* slot_qb, const float* slot_qd,
+                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s);
 
 // ivf.hip
 void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,

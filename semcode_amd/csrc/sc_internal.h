@@ -94,8 +94,7 @@ struct sc_index {
     void* ivf_scratch = nullptr; size_t ivf_scratch_cap = 0;
     // int8 coarse stage of list-major probing (L2; ivf_coarse.hip): every list quantised relative to its centroid
     void* Xc8 = nullptr;     size_t xc8_cap = 0;  // [ivf_rows padded to 256][ld8] int8 of x - c_list
-    float* xcs = nullptr;                         // [rows] scale,  xcn: [rows] |x - c_list|^2  (one allocation: xcs | xcn)
-    float* xcn = nullptr;    size_t xcsn_cap = 0;
+    float* xcs = nullptr;    size_t xcsn_cap = 0; // [rows][4] f32 per row: {|x - c_list|^2, int8 scale, 2 |dx|, 2 (|x'| + |dx|)}
     unsigned* list_stats = nullptr;               // [nlist][2] bits of {max |x' - xq|^2, max |x'|^2} + [4] bits of max |x|^2 behind them
     int64_t shadowc_rows = 0;                     // rows covered by the centred shadow (== ivf_rows when valid)
     void* ivfc_scratch = nullptr; size_t ivfc_scratch_cap = 0;

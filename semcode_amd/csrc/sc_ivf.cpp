@@ -826,15 +826,13 @@ static sc_status ivfc_ensure_shadow(sc_index* ix) {
     const int64_t rows = ix->ivf_rows, rows_pad = (rows + 255) / 256 * 256 + 256;  // (a list's last tile reads up to 255 rows beyond its end)
     sc_status st = sc_grow(ix, &ix->Xc8, &ix->xc8_cap, (size_t)rows_pad * ld8);
     if (st) return st;
-    st = sc_grow(ix, (void**)&ix->xcs, &ix->xcsn_cap, (size_t)rows_pad * 8);
+    st = sc_grow(ix, (void**)&ix->xcs, &ix->xcsn_cap, (size_t)rows_pad * 16);
     if (st) return st;
-    ix->xcn = ix->xcs + rows_pad;
     if (!ix->list_stats) SC_HIP(hipMalloc((void**)&ix->list_stats, ((size_t)ix->nlist * 2 + 4) * 4));
     SC_HIP(hipMemsetAsync(ix->list_stats, 0, ((size_t)ix->nlist * 2 + 4) * 4, s));
     SC_HIP(hipMemsetAsync((char*)ix->Xc8 + (size_t)rows * ld8, 0, (size_t)(rows_pad - rows) * ld8, s));
-    SC_HIP(hipMemsetAsync(ix->xcs + rows, 0, (size_t)(rows_pad - rows) * 4, s));
-    SC_HIP(hipMemsetAsync(ix->xcn + rows, 0, (size_t)(rows_pad - rows) * 4, s));
-    sc_launch_ivf_center_shadow(ix->X, rows, ix->ld, ld8, ix->quant->X, ix->quant->ld, ix->list_off, nlist, ix->Xc8, ix->xcs, ix->xcn, ix->list_stats, s);
+    SC_HIP(hipMemsetAsync(ix->xcs + rows * 4, 0, (size_t)(rows_pad - rows) * 16, s));
+    sc_launch_ivf_center_shadow(ix->X, rows, ix->ld, ld8, ix->quant->X, ix->quant->ld, ix->list_off, nlist, ix->Xc8, ix->xcs, ix->list_stats, s);
     sc_launch_norm_max(ix->xnorm, rows, ix->list_stats + (size_t)ix->nlist * 2, s);  // bits of max |x|^2: the re-rank's rounding allowance
     SC_HIP(hipGetLastError());
     ix->shadowc_rows = rows;
@@ -926,7 +924,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const int Qpad = (Q + 255) / 256 * 256;
     const size_t o_sq = carve((size_t)nslots * 4), o_sl = carve((size_t)nslots * 4), o_qs = carve((size_t)nslots * 4), o_qn = carve((size_t)nslots * 4),
-                 o_st = carve((size_t)nslots * 4), o_stf = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
+                 o_st = carve((size_t)nslots * 4), o_stf = carve((size_t)nslots * 4), o_qb = carve((size_t)nslots * 4), o_qd = carve((size_t)nslots * 4),
+                 o_se = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
                  o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
                  o_qres = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8), o_ek = carve((size_t)Q * KP * 8), o_surv = carve((size_t)Q * IVFC_CAP * 8);
     const size_t hit_bytes = (size_t)2048 * (4 + 8192 * 16) + 256;
@@ -935,7 +934,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     if (st) return st;
     char* b = (char*)ix->ivfc_scratch;
     int32_t *d_sq = (int32_t*)(b + o_sq), *d_sl = (int32_t*)(b + o_sl);
-    float *d_qs = (float*)(b + o_qs), *d_qn = (float*)(b + o_qn), *d_st = (float*)(b + o_st), *d_stf = (float*)(b + o_stf);
+    float *d_qs = (float*)(b + o_qs), *d_qn = (float*)(b + o_qn), *d_st = (float*)(b + o_st), *d_stf = (float*)(b + o_stf), *d_qb = (float*)(b + o_qb),
+          *d_qd = (float*)(b + o_qd), *d_se = (float*)(b + o_se);
     float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf), *qres = (float*)(b + o_qres);
     unsigned* cnt = (unsigned*)(b + o_cnt);
     int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
@@ -950,7 +950,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, s);
+    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
     SC_HIP(hipMemsetAsync(qres, 0, (size_t)Q * 4, s));
     // 4. the two phases
@@ -959,10 +959,10 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     for (int ph = 0; ph < 2; ++ph) {
         const int ni = (int)items[ph].size();
         if (ni > 0) {
-            sc_launch_ivf_slot_thr(d_sq, d_qn, thr, nslots, d_st, d_stf, s);
+            sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
             sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-            sc_launch_ivf_coarse(ix->Xc8, ix->xcn, ix->xcs, ld8, b + o_qc, b + o_items + item0 * sizeof(Item), ni, d_stf, d_st, d_qn, d_qs, d_sq, surv, cnt, IVFC_CAP,
-                                 b + o_hits, hit_bytes, s);
+            sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + item0 * sizeof(Item), ni, d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, surv, cnt,
+                                 IVFC_CAP, b + o_hits, hit_bytes, s);
             sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
             sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
             sc_launch_scan_select(SC_METRIC_L2, surv, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
@@ -984,30 +984,44 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     const int R = (int)redo.size();
     ix->last_ivfc_uncertified = R;
     ix->last_uncertified = R;
+    static const bool trace_c = getenv("SC_IVF_TRACE") != nullptr;  // tuning aid
+    if (trace_c) {
+        std::vector<int> hovf(Q);
+        std::vector<unsigned> hcnt(Q);
+        std::vector<float> hthr(Q);
+        SC_HIP(hipMemcpy(hovf.data(), ovf, (size_t)Q * 4, hipMemcpyDeviceToHost));
+        SC_HIP(hipMemcpy(hthr.data(), thr, (size_t)Q * 4, hipMemcpyDeviceToHost));
+        int novf = 0, ninf = 0;
+        for (int i = 0; i < Q; ++i) { novf += hovf[i] != 0; ninf += !(hthr[i] < 1e30f); }
+        int ja_max = 0;
+        double ja_sum = 0;
+        for (int i = 0; i < Q; ++i) { ja_max = std::max(ja_max, ja[(size_t)i]); ja_sum += ja[(size_t)i]; }
+        fprintf(stderr, "[ivf coarse] Q %d: uncertified %d (survivor overflow %d, threshold still +inf %d); phase A lists per query avg %.2f max %d; items %zu + %zu, slots %d; "
+                        "streamed %.1f GB int8\n", Q, R, novf, ninf, ja_sum / Q, ja_max, items[0].size(), items[1].size(), nslots, (double)streamed_rows * ld8 / 1e9);
+    }
     if (ix->search_mode == 0 && Q >= 32 && R * 4 > Q) ix->ivfc_off = true;  // this index does not quantise well enough: later batches probe exactly
     ix->last_probed_lists = nprobe;
     ix->last_unique_rows = unique_rows;
     ix->last_streamed_rows = streamed_rows;
     ix->last_groups = (int)(nslots / 64);
     if (R > 0) {  // probed again exactly: the sub-batch gets its own staging (queries + results)
-        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255;
-        st = sc_grow(ix, &ix->fb, &ix->fb_cap, qb + db + (size_t)R * k * 8);
+        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255, rb = ((size_t)R * k * 8 + 255) & ~(size_t)255;
+        st = sc_grow(ix, &ix->fb, &ix->fb_cap, qb + db + rb + (size_t)R * 4);
         if (st) return st;
         float* fq = (float*)ix->fb;
         float* fd = (float*)((char*)ix->fb + qb);
         int64_t* frw = (int64_t*)((char*)ix->fb + qb + db);
-        for (int j = 0; j < R; ++j)
-            SC_HIP(hipMemcpyAsync(fq + (size_t)j * ix->dim, q_dev + (size_t)redo[j] * ix->dim, (size_t)ix->dim * 4, hipMemcpyDeviceToDevice, s));
+        int32_t* fidx = (int32_t*)((char*)ix->fb + qb + db + rb);
+        SC_HIP(hipMemcpyAsync(fidx, redo.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+        sc_launch_copy_rows_indexed(q_dev, fq, fidx, R, (size_t)ix->dim * 4, false, s);
         const int saved_mode = ix->search_mode;
         ix->search_mode = 4;
         if (R >= 2) st = sc_ivf_search_listmajor_locked(ix, fq, R, k, nprobe, fd, frw);
         else st = sc_ivf_search_locked(ix, fq, R, k, nprobe, fd, frw);
         ix->search_mode = saved_mode;
         if (st) return st;
-        for (int j = 0; j < R; ++j) {
-            SC_HIP(hipMemcpyAsync(out_dist + (size_t)redo[j] * k, fd + (size_t)j * k, (size_t)k * 4, hipMemcpyDeviceToDevice, s));
-            SC_HIP(hipMemcpyAsync(out_rows + (size_t)redo[j] * k, frw + (size_t)j * k, (size_t)k * 8, hipMemcpyDeviceToDevice, s));
-        }
+        sc_launch_copy_rows_indexed(fd, out_dist, fidx, R, (size_t)k * 4, true, s);
+        sc_launch_copy_rows_indexed(frw, out_rows, fidx, R, (size_t)k * 8, true, s);
         SC_HIP(hipStreamSynchronize(s));
         ix->last_ivfc_uncertified = R;
         ix->last_uncertified = R;

@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
 #define C64_STAGE_W (64 * 128)
 #define C64_STAGE (C64_STAGE_A + C64_STAGE_W)
 #define C64_RING (3 * C64_STAGE)
-#define C64_LDS_BYTES (C64_RING + 3 * 512 * 4 + 3 * 512 * 4 + 4 * 64 * 4)
+#define C64_LDS_BYTES (C64_RING + 3 * 1024 * 4 + 1024 * 4 + 3 * 512 * 4 + 4 * 64 * 4)
 // GROUPED (IVF_FLAT coarse stage, ivf_coarse.hip): a work item is one 256-row tile of a LIST PART against one group of up to 64
 // query SLOTS (the (query, list) pairs that probe the list): rows from the centred int8 shadow, slots from the per-pair centred
 // queries, thresholds / norms / scales / query ids per slot.  Same stream of stages, same tests; a hit names the slot's query.
@@ -1065,6 +1065,8 @@ struct GroupedArgs {
     int nitems;
     const float *slot_tf, *slot_thr, *slot_qn, *slot_qs;
     const int32_t* slot_q;
+    const float *slot_qb, *slot_qd;  // |q'|, |q' - qq|: the pair factors of the row-wise error bound
+    const f32x4* xrow;               // per row {|x'|^2, scale, 2 |dx|, 2 (|x'| + |dx|)}
 };
 template <int METRIC, bool GROUPED = false>
 __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4_t* __restrict__ hitlist, unsigned* __restrict__ hitcount, int hitcap, GroupedArgs ga) {
@@ -1082,9 +1084,11 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
     const int64_t mine = (ntiles - first + gridDim.x - 1) / gridDim.x, S = mine * nk;
     // [3][xnorm 256 | xscale 256]: a tile's row side is requested two stages ahead, i.e. (one stage per tile, ld8 = 128) while the
     // epilogue of the tile two before it is still reading its copy -- three copies; the slot side (GROUPED) likewise
+    // GROUPED: the row side is one 16-byte record per row ([3][256] f32x4 + 4 KiB that take the second copy waves 4-7 request so that
+    // every wave issues the same number of pieces)
     float* rowlds = reinterpret_cast<float*>(smem + C64_RING);
-    float* slotlds = rowlds + 3 * 512;  // GROUPED: [3][8][64]: tf | thr | qn | qs | query id | (3 unused)
-    float* qlds = slotlds + 3 * 512;    // flat: thr_fast[64] | thr[64] | qnorm[64] | qscale[64]
+    float* slotlds = rowlds + 3 * 1024 + 1024;  // GROUPED: [3][8][64]: tf | thr | qn | qs | query id | |q'| | |dq| | (unused)
+    float* qlds = slotlds + 3 * 512;            // flat: thr_fast[64] | thr[64] | qnorm[64] | qscale[64]
     if (!GROUPED && tid < 64) {
         const bool real = tid < a.Q;
         qlds[tid] = real ? a.thr_fast[tid] : -__builtin_inff();
@@ -1109,10 +1113,9 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
     const float* rowsrc = w < 4 ? a.xnorm : a.xscale;
     const uint32_t vrow = (uint32_t)(((w & 3) * 64 + lane) * 4);
     const float* slotsrc = nullptr;  // GROUPED: wave w requests slot array w % 5 of the item (256 B)
-    if (GROUPED) {
-        const int k = w < 5 ? w : w - 5;
-        slotsrc = k == 0 ? ga.slot_tf : k == 1 ? ga.slot_thr : k == 2 ? ga.slot_qn : k == 3 ? ga.slot_qs : reinterpret_cast<const float*>(ga.slot_q);
-    }
+    if (GROUPED)
+        slotsrc = w == 0 ? ga.slot_tf : w == 1 ? ga.slot_thr : w == 2 ? ga.slot_qn : w == 3 ? ga.slot_qs : w == 4 ? reinterpret_cast<const float*>(ga.slot_q)
+                  : w == 5 ? ga.slot_qb : w == 6 ? ga.slot_qd : ga.slot_tf;
 
     int64_t t_i = first;  // issue side: tile and K-tile of the next stage to request
     int kt_i = 0, j_i = 0;
@@ -1133,8 +1136,14 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                 const int64_t left = a.row1 - m0_i;
                 rows_i = (int)(left >= 256 ? 256 : left > 0 ? left : 0);
             }
-            const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(rowsrc + m0_i), 0, rows_i * 4, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_vptr)(reinterpret_cast<char*>(rowlds) + ((j_i % 3) * 512 + (w >> 2) * 256 + (w & 3) * 64) * 4), 4, vrow, 0, 0, 0);
+            if (GROUPED) {  // 64 row records of 16 B per wave (waves 4-7: the same rows again, into the spare 4 KiB)
+                const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(ga.xrow + m0_i), 0, rows_i * 16, 0x00020000);
+                char* rdst = reinterpret_cast<char*>(rowlds) + (w < 4 ? (j_i % 3) * 4096 : 3 * 4096) + (w & 3) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_vptr)rdst, 16, (uint32_t)(((w & 3) * 64 + lane) * 16), 0, 0, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void*)(rowsrc + m0_i), 0, rows_i * 4, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_vptr)(reinterpret_cast<char*>(rowlds) + ((j_i % 3) * 512 + (w >> 2) * 256 + (w & 3) * 64) * 4), 4, vrow, 0, 0, 0);
+            }
         }
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Xb) + m0_i * (int64_t)ld8), 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.Qb) + (int64_t)sb_i * ld8), 0, -1, 0x00020000);
@@ -1203,8 +1212,8 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
             const int64_t left = a.row1 - m0;
             rows_c = (int)(left >= 256 ? 256 : left);
         }
-        const float* rs = rowlds + (j_c % 3) * 512;
-        const float* sl = GROUPED ? slotlds + (j_c % 3) * 512 : qlds;  // tf | thr | qn | qs (| query id)
+        const float* rs = rowlds + (j_c % 3) * (GROUPED ? 1024 : 512);
+        const float* sl = GROUPED ? slotlds + (j_c % 3) * 512 : qlds;  // tf | thr | qn | qs (| query id | |q'| | |dq|)
         f32x4 tf[4], sq[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -1216,7 +1225,14 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
             const int rl = 32 * w + 16 * mi + fr;
             const int64_t row = m0 + rl;
             const bool rowok = rl < rows_c;
-            const float xn = rs[rl], sx = rs[256 + rl];
+            float xn, sx, ea = 0.f, ec = 0.f;  // GROUPED: ea = 2 |dx_r|, ec = 2 (|x'_r| + |dx_r|)
+            if (GROUPED) {
+                const f32x4 rec = *reinterpret_cast<const f32x4*>(rs + 4 * rl);
+                xn = rec[0]; sx = rec[1]; ea = rec[2]; ec = rec[3];
+            } else {
+                xn = rs[rl];
+                sx = rs[256 + rl];
+            }
             const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
             const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
 #pragma unroll
@@ -1237,7 +1253,8 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                     const int ql = 16 * ni + 4 * fq + r;
                     if (rowok && t[r] <= tf[ni][r]) {
                         const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
-                        const float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
+                        float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
+                        if (GROUPED) sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc));  // the row's own error bound: a lower bound of the exact distance
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= sl[64 + ql]) {  // -inf for padded slots
                             h = true;
@@ -1300,17 +1317,17 @@ static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scrat
 }
 // IVF_FLAT coarse stage (L2): `nitems` work items {row0, rows, slot_base} over the centred int8 shadow Xc8 / per-pair queries Qc8; per-slot
 // thresholds etc.; hits go to the survivor lists of the slots' queries.  hit_scratch as for the flat form.
-void sc_launch_ivf_coarse(const void* Xc8, const float* xcn, const float* xcs, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
-                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, uint64_t* surv, unsigned* count, int cap,
-                          void* hit_scratch, size_t hit_bytes, hipStream_t s) {
+void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
+                          const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, const float* slot_qb, const float* slot_qd,
+                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s) {
     if (nitems <= 0) return;
     static ScDeviceOnce once;
     sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
     CoarseArgs a;
-    a.Xb = (const bf16_t*)Xc8; a.xnorm = xcn; a.xscale = xcs; a.row0 = 0; a.row1 = 0; a.ld = ld8 / 2; a.Qb = (const bf16_t*)Qc8; a.qnorm = nullptr; a.Q = 0; a.qtiles = 1;
+    a.Xb = (const bf16_t*)Xc8; a.xnorm = nullptr; a.xscale = nullptr; a.row0 = 0; a.row1 = 0; a.ld = ld8 / 2; a.Qb = (const bf16_t*)Qc8; a.qnorm = nullptr; a.Q = 0; a.qtiles = 1;
     a.thr = nullptr; a.thr_fast = nullptr; a.surv = surv; a.count = count; a.cap = cap; a.ntiles = nitems; a.qscale = nullptr; a.trace = nullptr;
     GroupedArgs ga;
-    ga.items = (const GroupItem*)items; ga.nitems = nitems; ga.slot_tf = slot_tf; ga.slot_thr = slot_thr; ga.slot_qn = slot_qn; ga.slot_qs = slot_qs; ga.slot_q = slot_q;
+    ga.items = (const GroupItem*)items; ga.nitems = nitems; ga.slot_tf = slot_tf; ga.slot_thr = slot_thr; ga.slot_qn = slot_qn; ga.slot_qs = slot_qs; ga.slot_q = slot_q; ga.slot_qb = slot_qb; ga.slot_qd = slot_qd; ga.xrow = (const f32x4*)xrow;
     const int cus = sc_device_cus();
     const int wgs = std::min(nitems, g_coarse_wgs > 0 ? g_coarse_wgs : cus);
     const size_t lists = (size_t)wgs * 8, off = (lists * 4 + 255) & ~(size_t)255;
