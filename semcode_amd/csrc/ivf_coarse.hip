@@ -18,6 +18,8 @@
 //   ivf_center_shadow_kernel : Xc8 [rows][ld8] int8 of x', per row {|x'|^2, scale, 2 |dx|, 2 (|x'| + |dx|)}, per-list maxima of |dx|^2 and |x'|^2
 //   ivf_pair_query_kernel    : per slot (query, list): int8 q', scale, |q'|^2 - eps  (the lower-bound form of the query norm)
 //   ivf_slot_thr_kernel      : per slot thresholds from the per-query ones, before every phase
+//   ivf_bound / ivf_candidates / ivf_refine_finalize : bound and refine (below): the exact re-rank of every row whose lower bound does not
+//                              exceed an upper bound of the k-th distance
 #include "sc_common.h"
 
 // lists[nlist + 1] ascending: the list whose range holds stored position r
@@ -193,4 +195,146 @@ void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const
                             hipStream_t s) {
     if (nslots <= 0) return;
     hipLaunchKernelGGL(ivf_slot_thr_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, slot_q, slot_qnlb, slot_eps, thr, nslots, slot_thr, slot_tf);
+}
+
+// ---- bound and refine ---------------------------------------------------------------------------------------------------------------
+// Round-3 first form kept the kp = 512 best lower bounds of a query and certified the result when the k-th exact distance lay below
+// the 512th lower bound; 124 .. 175 of 1024 queries at config 5 failed that test (more than 512 rows of their own cluster have lower
+// bounds below d_k: int8 cannot tell them apart) and their exact re-probe cost 6.0 of the batch's 14.2 ms.  The bound that matters is
+// not the kp-th LOWER bound but an UPPER bound of d_k, and phase A provides one almost for free:
+//   phase A   every row of the query's nearest list(s): lower-bound keys, all kept (survA; dense, no test);
+//             its kpa = 128 best are re-scored exactly: their k-th exact distance dA >= d_k, and T = dA + allowance;
+//   phase B   the other lists: a row survives iff lower bound <= T (survB);
+//   refine    S = {survA \ the 128 already done : lower bound <= T} + survB is re-scored exactly; exact top-k of (the 128 + S).
+// Every probed row outside S has exact distance >= lower bound > T >= d_k: the result is the exact probe's, bit for bit, with no
+// candidate count to exceed -- only |S| > IVFW_CAP or an overflowing survivor list send a query to the exact probe.
+// The allowance is the certificate's own (f32 rounding of the exact scores; scan_batched.hip certified<>).
+#define IVFW_CAP 4096
+int sc_ivf_widen_cap(void) { return IVFW_CAP; }
+
+static __device__ __forceinline__ float ivf_rounding_allowance(const unsigned* __restrict__ xmax_bits, float qnorm2, int ld) {
+    const float xmax = sqrtf(__builtin_bit_cast(float, xmax_bits[0])), qn = sqrtf(qnorm2);
+    return (2.0f * (float)ld * 1.2e-7f * xmax * qn) * 1.01f + 1e-6f;
+}
+
+// T[q] = (k-th smallest exact distance among the kpa re-scored phase-A candidates) + allowance; +inf if there are fewer than k
+__global__ __launch_bounds__(128) void ivf_bound_kernel(const uint64_t* __restrict__ ekeysA, int kpa, int k, const float* __restrict__ qnorm,
+                                                         const unsigned* __restrict__ xmax_bits, int ld, float* __restrict__ thr) {
+    __shared__ uint64_t keys[512];
+    __shared__ float s_t;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < kpa; i += 128) keys[i] = ekeysA[(size_t)q * kpa + i];
+    if (tid == 0) s_t = __builtin_inff();
+    __syncthreads();
+    for (int i = tid; i < kpa; i += 128) {
+        const uint64_t key = keys[i];
+        if (key == SC_KEY_MAX) continue;
+        int rank = 0;
+        for (int j = 0; j < kpa; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
+        if (rank == k - 1) s_t = sc_key_score(SC_METRIC_L2, key) + ivf_rounding_allowance(xmax_bits, qnorm[q], ld);
+    }
+    __syncthreads();
+    if (tid == 0) thr[q] = s_t;
+}
+
+// S of one query -> cand [q][IVFW_CAP], ncand[q]; flags[q] = 1 (exact probe) when a survivor list overflowed or S does not fit
+__global__ __launch_bounds__(256) void ivf_candidates_kernel(const uint64_t* __restrict__ survA, const unsigned* __restrict__ cntA, const uint64_t* __restrict__ bestA, int kpa,
+                                                              const uint64_t* __restrict__ survB, const unsigned* __restrict__ cntB, int cap,
+                                                              const float* __restrict__ thr, uint64_t* __restrict__ cand, int* __restrict__ ncand,
+                                                              int* __restrict__ flags, int wcap) {
+    __shared__ unsigned s_n;
+    __shared__ uint64_t wmax[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    const unsigned nA = cntA[q], nB = cntB[q];
+    const float T = thr[q];
+    if (nA > (unsigned)cap || nB > (unsigned)cap || !(T < __builtin_inff())) {  // uniform over the workgroup
+        if (tid == 0) { ncand[q] = 0; flags[q] = 1; }
+        return;
+    }
+    // the largest key of bestA: survA keys up to it are the kpa that have been re-scored already
+    uint64_t m = 0;
+    for (int i = tid; i < kpa; i += 256) {
+        const uint64_t key = bestA[(size_t)q * kpa + i];
+        if (key != SC_KEY_MAX && key > m) m = key;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = ((uint64_t)__shfl_xor((unsigned)(m >> 32), off, 64) << 32) | (uint64_t)__shfl_xor((unsigned)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    uint64_t pivot = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) pivot = wmax[w] > pivot ? wmax[w] : pivot;
+    for (unsigned i = tid; i < nA + nB; i += 256) {
+        const bool fromA = i < nA;
+        const uint64_t key = fromA ? survA[(size_t)q * cap + i] : survB[(size_t)q * cap + (i - nA)];
+        if (fromA && key <= pivot) continue;
+        if (sc_key_score(SC_METRIC_L2, key) <= T) {
+            const unsigned pos = atomicAdd(&s_n, 1u);
+            if (pos < (unsigned)wcap) cand[(size_t)q * IVFW_CAP + pos] = key;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool fits = s_n <= (unsigned)wcap;
+        ncand[q] = fits ? (int)s_n : 0;
+        flags[q] = fits ? 0 : 1;
+    }
+}
+
+// exact keys of the kpa + ncand[q] re-scored rows -> the k best, in order (flagged queries are left to the exact probe)
+__global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(const uint64_t* __restrict__ ekeysA, int kpa, const uint64_t* __restrict__ ekeys, const int* __restrict__ ncand,
+                                                                   const int* __restrict__ flags, int k, int64_t row_base, float* __restrict__ out_dist,
+                                                                   int64_t* __restrict__ out_rows) {
+    __shared__ uint64_t keys[IVFW_CAP + 512];
+    __shared__ uint64_t wmin[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (flags[q]) return;
+    const int n = kpa + ncand[q];
+    for (int i = tid; i < n; i += 256) keys[i] = i < kpa ? ekeysA[(size_t)q * kpa + i] : ekeys[(size_t)q * IVFW_CAP + (i - kpa)];
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        uint64_t m = SC_KEY_MAX;
+        for (int i = tid; i < n; i += 256) m = keys[i] < m ? keys[i] : m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint64_t o = ((uint64_t)__shfl_xor((unsigned)(m >> 32), off, 64) << 32) | (uint64_t)__shfl_xor((unsigned)m, off, 64);
+            m = o < m ? o : m;
+        }
+        if ((tid & 63) == 0) wmin[tid >> 6] = m;
+        __syncthreads();
+        uint64_t b = wmin[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = wmin[w] < b ? wmin[w] : b;
+        if (tid == 0) {
+            const size_t o = (size_t)q * k + j;
+            if (b != SC_KEY_MAX) {
+                out_dist[o] = sc_key_score(SC_METRIC_L2, b);
+                out_rows[o] = row_base + (int64_t)(uint32_t)b;
+            } else {
+                out_dist[o] = __builtin_inff();
+                out_rows[o] = -1;
+            }
+        }
+        if (b != SC_KEY_MAX)
+            for (int i = tid; i < n; i += 256)
+                if (keys[i] == b) keys[i] = SC_KEY_MAX;
+        __syncthreads();
+    }
+}
+
+void sc_launch_ivf_bound(const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_bound_kernel, dim3((unsigned)Q), dim3(128), 0, s, ekeysA, kpa, k, qnorm, xmax_bits, ld, thr);
+}
+void sc_launch_ivf_candidates(const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
+                              const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_candidates_kernel, dim3((unsigned)Q), dim3(256), 0, s, survA, cntA, bestA, kpa, survB, cntB, cap, thr, cand, ncand, flags,
+                       wcap < IVFW_CAP ? wcap : IVFW_CAP);
+}
+void sc_launch_ivf_refine_finalize(const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist,
+                                   int64_t* out_rows, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
 }

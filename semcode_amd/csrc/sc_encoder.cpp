@@ -672,12 +672,14 @@ void sc_launch_gemm_i8_diag(const void* A, const void* W, void* C, int M, int N,
 void sc_scan_set_coarse_workgroups(int v);
 void sc_scan_set_coarse_persistent(int v);
 void sc_ivf_set_refresh_nomem(int v);
+void sc_ivf_set_refine_cap(int v);
 extern "C" sc_status sc_diag_set_option(const char* name, int32_t value) {
     if (!name) return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: NULL name");
     if (!strcmp(name, "coarse_workgroups")) sc_scan_set_coarse_workgroups(value);
     else if (!strcmp(name, "coarse_persistent")) sc_scan_set_coarse_persistent(value);
     else if (!strcmp(name, "gemm_pp")) sc_gemm_set_pp(value);
     else if (!strcmp(name, "ivf_refresh_nomem")) sc_ivf_set_refresh_nomem(value);
+    else if (!strcmp(name, "ivf_refine_cap")) sc_ivf_set_refine_cap(value);
     else return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: unknown option '%s'", name);
     return SC_OK;
 }

@@ -173,6 +173,8 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<i
 // build from scratch for these centroids.  Called at the start of every search; caller holds ix->mu.
 static int g_ivf_refresh_nomem = 0;  // sc_diag_set_option("ivf_refresh_nomem", 1): tests of the fallback below
 void sc_ivf_set_refresh_nomem(int v) { g_ivf_refresh_nomem = v; }
+static int g_ivf_refine_cap = 1 << 30;  // sc_diag_set_option("ivf_refine_cap", n): the coarse stage's refine step takes on at most n rows per query (tests of the exact re-probe)
+void sc_ivf_set_refine_cap(int v) { g_ivf_refine_cap = v < 0 ? (1 << 30) : v; }
 
 sc_status sc_ivf_cover_tail_locked(sc_index* ix) {
     if (!ix->perm) return SC_OK;
@@ -797,16 +799,16 @@ extern "C" sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* cent
 
 // ---- list-major probing behind an int8 coarse stage (L2) ---------------------------------------------------------------------------
 // ivf_coarse.hip has the idea: every list quantised relative to its centroid, one centred int8 query per (query, probed list)
-// pair, coarse scores turned into lower bounds of the exact distance.  Here: the plan (pairs bucketed by list, groups of up to 64
-// query slots, one work item per 256-row tile of a list x group), two phases of the grouped streaming kernel
-// (scan_coarse64s_kernel<GROUPED>) with a selection of the 512 best lower bounds per query after each -- phase A: every query's
-// NEAREST list only (thresholds start at +inf: every row of it survives, and its 512th best is already a tight threshold because the
-// nearest cluster holds most of the neighbours); phase B: the other nprobe - 1 lists against those thresholds -- then the exact f32
-// re-rank of the candidates (canonical fmaf chain from the original rows: the distances of the exact paths) and the certificate:
-// k-th exact distance + the f32 rounding allowance < final threshold => no row of the probed lists that was dropped can be closer.
-// Uncertified queries (survivor-list overflow, too tight a gap) are probed again exactly (scan_listgemm / scan_exact kernels).
-// Results are therefore those of the exact list-major path, bit for bit.
-static const int IVFC_CAP = 8192;  // survivors per query and phase (a whole nearest list survives phase A)
+// pair, coarse scores turned into lower bounds of the exact distance, then bound and refine.  Here: the plan (pairs bucketed by
+// list, groups of up to 64 query slots, one work item per 256-row tile of a list x group) and the sequence
+//   phase A  every query's NEAREST list(s) through the grouped streaming kernel (scan_coarse64s_kernel<GROUPED, DENSE>): all lower-bound
+//            keys kept; the 128 best re-scored exactly (canonical fmaf chain from the original rows) -> T = k-th exact distance + allowance;
+//   phase B  the other nprobe - 1 lists: rows with lower bound <= T survive;
+//   refine   all survivors of both phases within T re-scored exactly, exact top-k.
+// No probed row outside the re-scored set can be closer than the k-th result, so the results are those of the exact list-major path,
+// bit for bit.  Queries whose survivor lists overflow or whose refine set exceeds 4096 rows are probed again exactly
+// (scan_listgemm / scan_exact kernels).
+static const int IVFC_CAP = 8192;  // survivors per query and phase (the whole of the nearest list(s) in phase A)
 static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
 
 bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
@@ -868,7 +870,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     // 2. plan.  Phase A = rank 0 of every query, phase B = the other ranks; per phase the pairs are bucketed by list (queries in
     // ascending order: deterministic), cut into groups of 64 slots, and every group meets every 256-row tile of its list.
     struct Item { long long row0; int rows; int slot_base; };
-    std::vector<int32_t> slot_q, slot_l;
+    std::vector<int32_t> slot_q, slot_l, slot_dst;  // slot_dst (phase A): where the list's rows go in the query's survivor list
+    std::vector<unsigned> cntA((size_t)Q, 0u);       // rows of every query's phase-A lists
     std::vector<Item> items[2];
     int64_t streamed_rows = 0, unique_rows = 0;
     std::vector<char> touched((size_t)nlist, 0);
@@ -909,8 +912,15 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
                 const int nq = std::min(64, m - c);
                 const int slot_base = (int)slot_q.size();
                 for (int sl = 0; sl < 64; ++sl) {
-                    slot_q.push_back(sl < nq ? qs[(size_t)start[(size_t)l] + c + sl] : -1);
+                    const int q = sl < nq ? qs[(size_t)start[(size_t)l] + c + sl] : -1;
+                    slot_q.push_back(q);
                     slot_l.push_back(sl < nq ? l : -1);
+                    int32_t dst = 0;
+                    if (ph == 0 && q >= 0) {
+                        dst = (int32_t)((uint32_t)cntA[(size_t)q] - (uint32_t)first);  // position of stored row r: (uint32)(r + dst)
+                        cntA[(size_t)q] = (unsigned)std::min<int64_t>((int64_t)cntA[(size_t)q] + (end - first), (int64_t)1 << 30);
+                    }
+                    slot_dst.push_back(dst);
                 }
                 for (int64_t r0 = first; r0 < end; r0 += 256) items[ph].push_back({(long long)r0, (int)std::min<int64_t>(256, end - r0), slot_base});
                 streamed_rows += end - first;
@@ -919,29 +929,35 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     }
     const int nslots = (int)slot_q.size();
     const size_t nitems = items[0].size() + items[1].size();
-    // 3. scratch: slot tables, per-pair queries, the batched path's per-query state, hit lists
+    // 3. scratch: slot tables, per-pair queries, per-query state, survivor lists of both phases, hit lists, the refine stage's sets
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const int Qpad = (Q + 255) / 256 * 256;
+    const int kpa = k <= sc_batched_kprime() / 2 ? sc_batched_kprime() : KP;  // phase-A candidates re-scored for the bound (128; 512 for k > 64)
+    const int WCAP = sc_ivf_widen_cap();
     const size_t o_sq = carve((size_t)nslots * 4), o_sl = carve((size_t)nslots * 4), o_qs = carve((size_t)nslots * 4), o_qn = carve((size_t)nslots * 4),
                  o_st = carve((size_t)nslots * 4), o_stf = carve((size_t)nslots * 4), o_qb = carve((size_t)nslots * 4), o_qd = carve((size_t)nslots * 4),
-                 o_se = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
-                 o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
-                 o_qres = carve((size_t)Q * 4), o_best = carve((size_t)Q * KP * 8), o_ek = carve((size_t)Q * KP * 8), o_surv = carve((size_t)Q * IVFC_CAP * 8);
+                 o_se = carve((size_t)nslots * 4), o_sd = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
+                 o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_cntA = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4),
+                 o_flag = carve((size_t)Q * 4), o_nc = carve((size_t)Q * 4), o_best = carve((size_t)Q * kpa * 8), o_ekA = carve((size_t)Q * kpa * 8),
+                 o_survA = carve((size_t)Q * IVFC_CAP * 8), o_survB = carve((size_t)Q * IVFC_CAP * 8), o_cand = carve((size_t)Q * WCAP * 8),
+                 o_ek2 = carve((size_t)Q * WCAP * 8);
     const size_t hit_bytes = (size_t)2048 * (4 + 8192 * 16) + 256;
     const size_t o_hits = carve(hit_bytes);
     st = sc_grow(ix, &ix->ivfc_scratch, &ix->ivfc_scratch_cap, off);
     if (st) return st;
     char* b = (char*)ix->ivfc_scratch;
-    int32_t *d_sq = (int32_t*)(b + o_sq), *d_sl = (int32_t*)(b + o_sl);
+    int32_t *d_sq = (int32_t*)(b + o_sq), *d_sl = (int32_t*)(b + o_sl), *d_sd = (int32_t*)(b + o_sd);
     float *d_qs = (float*)(b + o_qs), *d_qn = (float*)(b + o_qn), *d_st = (float*)(b + o_st), *d_stf = (float*)(b + o_stf), *d_qb = (float*)(b + o_qb),
           *d_qd = (float*)(b + o_qd), *d_se = (float*)(b + o_se);
-    float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf), *qres = (float*)(b + o_qres);
-    unsigned* cnt = (unsigned*)(b + o_cnt);
-    int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag);
-    uint64_t *best = (uint64_t*)(b + o_best), *ekeys = (uint64_t*)(b + o_ek), *surv = (uint64_t*)(b + o_surv);
+    float *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
+    unsigned *cnt = (unsigned*)(b + o_cnt), *cntA_d = (unsigned*)(b + o_cntA);
+    int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag), *ncand = (int*)(b + o_nc);
+    uint64_t *best = (uint64_t*)(b + o_best), *ekeysA = (uint64_t*)(b + o_ekA), *survA = (uint64_t*)(b + o_survA), *survB = (uint64_t*)(b + o_survB),
+             *cand2 = (uint64_t*)(b + o_cand), *ekeys2 = (uint64_t*)(b + o_ek2);
     SC_HIP(hipMemcpyAsync(d_sq, slot_q.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, s));
     SC_HIP(hipMemcpyAsync(d_sl, slot_l.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(d_sd, slot_dst.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, s));
     if (!items[0].empty()) SC_HIP(hipMemcpyAsync(b + o_items, items[0].data(), items[0].size() * sizeof(Item), hipMemcpyHostToDevice, s));
     if (!items[1].empty())
         SC_HIP(hipMemcpyAsync(b + o_items + items[0].size() * sizeof(Item), items[1].data(), items[1].size() * sizeof(Item), hipMemcpyHostToDevice, s));
@@ -951,30 +967,41 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
     sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s);
-    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
-    SC_HIP(hipMemsetAsync(qres, 0, (size_t)Q * 4, s));
-    // 4. the two phases
+    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, kpa, s);
+    // phase A is dense: every row of its lists survives, at a known place of survA; the counts are known here
+    SC_HIP(hipMemcpyAsync(cnt, cntA.data(), (size_t)Q * 4, hipMemcpyHostToDevice, s));
+    SC_HIP(hipMemcpyAsync(cntA_d, cntA.data(), (size_t)Q * 4, hipMemcpyHostToDevice, s));
+    const unsigned* xmax_bits = ix->list_stats + (size_t)ix->nlist * 2;  // bits of max |x|^2: the rounding allowance of the exact scores
     hipEvent_t e0, e1;
-    size_t item0 = 0;
-    for (int ph = 0; ph < 2; ++ph) {
-        const int ni = (int)items[ph].size();
-        if (ni > 0) {
-            sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
-            sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-            sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + item0 * sizeof(Item), ni, d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, surv, cnt,
-                                 IVFC_CAP, b + o_hits, hit_bytes, s);
-            sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
-            sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-            sc_launch_scan_select(SC_METRIC_L2, surv, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
-            sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
-        }
-        item0 += items[ph].size();
+    // 4. phase A: lower bounds of the nearest list(s) -> the kpa best re-scored exactly -> T = their k-th exact distance + allowance
+    if (!items[0].empty()) {
+        sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);  // (+inf everywhere; the dense form tests nothing)
+        sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+        sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items, (int)items[0].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survA, cnt, IVFC_CAP,
+                             b + o_hits, hit_bytes, s, d_sd);
+        sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
     }
-    // 5. exact re-rank + certificate.  The thresholds are lower bounds already (the pair's error is inside the key), so the
-    // certificate only has to allow for the f32 rounding of the exact scores: bits = {max |x|^2, 0, 0}, |q - q~| = 0.
-    sc_launch_scan_rerank(SC_METRIC_L2, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, ix->list_stats + (size_t)ix->nlist * 2, qres, ovf, Q, k, ix->row_base,
-                          ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
+    sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+    sc_launch_scan_select(SC_METRIC_L2, survA, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, kpa, s);  // (resets cnt: phase B counts from 0)
+    sc_launch_scan_rerank_keys_l2(ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, nullptr, kpa, ix->perm, ekeysA, Q, s);
+    sc_launch_ivf_bound(ekeysA, kpa, k, ix->qnorm, xmax_bits, ld, thr, Q, s);
+    sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+    // 5. phase B: the other lists against T
+    if (!items[1].empty()) {
+        sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
+        sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+        sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + items[0].size() * sizeof(Item), (int)items[1].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb,
+                             d_qd, survB, cnt, IVFC_CAP, b + o_hits, hit_bytes, s);
+        sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+    }
+    // 6. refine: every row whose lower bound is within T, re-scored exactly; exact top-k
+    sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+    sc_launch_ivf_candidates(survA, cntA_d, best, kpa, survB, cnt, IVFC_CAP, thr, cand2, ncand, flags, Q, g_ivf_refine_cap < WCAP ? g_ivf_refine_cap : WCAP, s);
+    sc_launch_scan_rerank_keys_l2(ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, cand2, ncand, WCAP, ix->perm, ekeys2, Q, s);
+    sc_launch_ivf_refine_finalize(ekeysA, kpa, ekeys2, ncand, flags, k, ix->row_base, out_dist, out_rows, Q, s);
+    sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
     SC_HIP(hipGetLastError());
+    static const bool trace_c = getenv("SC_IVF_TRACE") != nullptr;  // tuning aid
     std::vector<int> hflags(Q);
     SC_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)Q * 4, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
@@ -984,20 +1011,29 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     const int R = (int)redo.size();
     ix->last_ivfc_uncertified = R;
     ix->last_uncertified = R;
-    static const bool trace_c = getenv("SC_IVF_TRACE") != nullptr;  // tuning aid
     if (trace_c) {
-        std::vector<int> hovf(Q);
-        std::vector<unsigned> hcnt(Q);
+        std::vector<int> hnc(Q);
+        std::vector<unsigned> hcb(Q);
         std::vector<float> hthr(Q);
-        SC_HIP(hipMemcpy(hovf.data(), ovf, (size_t)Q * 4, hipMemcpyDeviceToHost));
+        SC_HIP(hipMemcpy(hnc.data(), ncand, (size_t)Q * 4, hipMemcpyDeviceToHost));
+        SC_HIP(hipMemcpy(hcb.data(), cnt, (size_t)Q * 4, hipMemcpyDeviceToHost));
         SC_HIP(hipMemcpy(hthr.data(), thr, (size_t)Q * 4, hipMemcpyDeviceToHost));
-        int novf = 0, ninf = 0;
-        for (int i = 0; i < Q; ++i) { novf += hovf[i] != 0; ninf += !(hthr[i] < 1e30f); }
-        int ja_max = 0;
-        double ja_sum = 0;
-        for (int i = 0; i < Q; ++i) { ja_max = std::max(ja_max, ja[(size_t)i]); ja_sum += ja[(size_t)i]; }
-        fprintf(stderr, "[ivf coarse] Q %d: uncertified %d (survivor overflow %d, threshold still +inf %d); phase A lists per query avg %.2f max %d; items %zu + %zu, slots %d; "
-                        "streamed %.1f GB int8\n", Q, R, novf, ninf, ja_sum / Q, ja_max, items[0].size(), items[1].size(), nslots, (double)streamed_rows * ld8 / 1e9);
+        int novf = 0, ninf = 0, nc_max = 0, ja_max = 0;
+        double nc_sum = 0, cb_sum = 0, ca_sum = 0, ja_sum = 0;
+        for (int i = 0; i < Q; ++i) {
+            novf += hcb[i] > (unsigned)IVFC_CAP || cntA[(size_t)i] > (unsigned)IVFC_CAP;
+            ninf += !(hthr[i] < 1e30f);
+            nc_max = std::max(nc_max, hnc[i]);
+            nc_sum += hnc[i];
+            cb_sum += hcb[i];
+            ca_sum += cntA[(size_t)i];
+            ja_max = std::max(ja_max, ja[(size_t)i]);
+            ja_sum += ja[(size_t)i];
+        }
+        fprintf(stderr, "[ivf coarse] Q %d: to the exact probe %d (survivor overflow %d, bound +inf %d); re-scored per query %d + avg %.1f max %d; phase A rows avg %.0f, "
+                        "phase B survivors avg %.1f; phase A lists per query avg %.2f max %d; items %zu + %zu, slots %d; streamed %.1f GB int8\n",
+                Q, R, novf, ninf, kpa, nc_sum / Q, nc_max, ca_sum / Q, cb_sum / Q, ja_sum / Q, ja_max, items[0].size(), items[1].size(), nslots,
+                (double)streamed_rows * ld8 / 1e9);
     }
     if (ix->search_mode == 0 && Q >= 32 && R * 4 > Q) ix->ivfc_off = true;  // this index does not quantise well enough: later batches probe exactly
     ix->last_probed_lists = nprobe;

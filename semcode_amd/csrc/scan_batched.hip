@@ -755,14 +755,17 @@ __global__ __launch_bounds__(KPRIME) void scan_rerank_kernel(const float* __rest
                                                           const int* __restrict__ overflow, int k,
                                                           int64_t row_base, const uint32_t* __restrict__ perm, float* __restrict__ out_dist,
                                                           int64_t* __restrict__ out_rows, int* __restrict__ flags, int kp = KPRIME,
-                                                          uint64_t* __restrict__ ekeys = nullptr) {
+                                                          uint64_t* __restrict__ ekeys = nullptr, const int* __restrict__ ncand = nullptr) {
     static_assert(KPRIME == 128, "the cooperative tile load assumes 128 candidates = 128 threads");
     __shared__ uint64_t keys[KPRIME];
     __shared__ uint32_t rowid[KPRIME];
     __shared__ __attribute__((aligned(16))) float tile[KPRIME * RR_STRIDE];
     __shared__ __attribute__((aligned(16))) float qch[64];
     const int q = blockIdx.x, lane = threadIdx.x;
-    const uint64_t ck = best[(size_t)q * kp + (SPLIT ? blockIdx.y * KPRIME : 0) + lane];
+    // ncand (SPLIT; the widened re-rank of the IVF coarse stage): only the first ncand[q] of the kp slots hold keys
+    const int nc = (SPLIT && ncand) ? ncand[q] : kp;
+    if (SPLIT && (int)blockIdx.y * KPRIME >= nc) return;
+    const uint64_t ck = (SPLIT ? (int)blockIdx.y * KPRIME : 0) + lane < nc ? best[(size_t)q * kp + (SPLIT ? blockIdx.y * KPRIME : 0) + lane] : SC_KEY_MAX;
     rowid[lane] = ck != SC_KEY_MAX ? (uint32_t)ck : 0u;  // padding slots re-score row 0 and are discarded below
     __syncthreads();
     const int seg = lane & 15, r0 = lane >> 4;  // this thread fetches 16-byte piece `seg` of rows r0, r0 + 8, ...
@@ -1067,8 +1070,12 @@ struct GroupedArgs {
     const int32_t* slot_q;
     const float *slot_qb, *slot_qd;  // |q'|, |q' - qq|: the pair factors of the row-wise error bound
     const f32x4* xrow;               // per row {|x'|^2, scale, 2 |dx|, 2 (|x'| + |dx|)}
+    const int32_t* slot_dst;         // DENSE: survivor-list position of the slot's list row r = (uint32)(r + slot_dst) (mod 2^32)
 };
-template <int METRIC, bool GROUPED = false>
+// DENSE (GROUPED; phase A of the IVF coarse stage): the thresholds are still +inf, EVERY row of the list survives -- so a row's place in
+// the query's survivor list is known in advance (its offset in the list + what the query's earlier lists hold) and the key goes
+// straight there: no test, no hit list, no atomics (the hit lists + their scatter cost 1.3 ms of a config-5 batch, all of it phase A).
+template <int METRIC, bool GROUPED = false, bool DENSE = false>
 __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4_t* __restrict__ hitlist, unsigned* __restrict__ hitcount, int hitcap, GroupedArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
     const float* slotsrc = nullptr;  // GROUPED: wave w requests slot array w % 5 of the item (256 B)
     if (GROUPED)
         slotsrc = w == 0 ? ga.slot_tf : w == 1 ? ga.slot_thr : w == 2 ? ga.slot_qn : w == 3 ? ga.slot_qs : w == 4 ? reinterpret_cast<const float*>(ga.slot_q)
-                  : w == 5 ? ga.slot_qb : w == 6 ? ga.slot_qd : ga.slot_tf;
+                  : w == 5 ? ga.slot_qb : w == 6 ? ga.slot_qd : reinterpret_cast<const float*>(ga.slot_dst);
 
     int64_t t_i = first;  // issue side: tile and K-tile of the next stage to request
     int kt_i = 0, j_i = 0;
@@ -1235,6 +1242,25 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
             }
             const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;
             const float ar = (METRIC == SC_METRIC_L2) ? -2.0f * sx : (METRIC == SC_METRIC_COSINE) ? -sx * xs : -sx;
+            if (GROUPED && DENSE) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = 16 * ni + 4 * fq + r;
+                        const int qid = __float_as_int(sl[256 + ql]);
+                        if (rowok && qid >= 0) {
+                            const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
+                            float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
+                            sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc));
+                            const uint32_t pos = (uint32_t)row + (uint32_t)__float_as_int(sl[448 + ql]);
+                            if (pos < (uint32_t)a.cap) a.surv[(size_t)qid * a.cap + pos] = sc_make_key<METRIC>(sc, (uint32_t)row);
+                        }
+                    }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 t;
@@ -1319,21 +1345,29 @@ static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scrat
 // thresholds etc.; hits go to the survivor lists of the slots' queries.  hit_scratch as for the flat form.
 void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
                           const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, const float* slot_qb, const float* slot_qd,
-                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s) {
+                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s, const int32_t* slot_dst) {
     if (nitems <= 0) return;
     static ScDeviceOnce once;
-    sc_device_once(once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES); });
+    sc_device_once(once, [&] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
+    });
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xc8; a.xnorm = nullptr; a.xscale = nullptr; a.row0 = 0; a.row1 = 0; a.ld = ld8 / 2; a.Qb = (const bf16_t*)Qc8; a.qnorm = nullptr; a.Q = 0; a.qtiles = 1;
     a.thr = nullptr; a.thr_fast = nullptr; a.surv = surv; a.count = count; a.cap = cap; a.ntiles = nitems; a.qscale = nullptr; a.trace = nullptr;
     GroupedArgs ga;
     ga.items = (const GroupItem*)items; ga.nitems = nitems; ga.slot_tf = slot_tf; ga.slot_thr = slot_thr; ga.slot_qn = slot_qn; ga.slot_qs = slot_qs; ga.slot_q = slot_q; ga.slot_qb = slot_qb; ga.slot_qd = slot_qd; ga.xrow = (const f32x4*)xrow;
+    ga.slot_dst = slot_dst ? slot_dst : slot_q;  // (wave 7 requests it either way)
     const int cus = sc_device_cus();
     const int wgs = std::min(nitems, g_coarse_wgs > 0 ? g_coarse_wgs : cus);
     const size_t lists = (size_t)wgs * 8, off = (lists * 4 + 255) & ~(size_t)255;
     unsigned* hitcount = (unsigned*)hit_scratch;
     u32x4_t* hitlist = (u32x4_t*)((char*)hit_scratch + off);
     const int hitcap = (int)std::min<size_t>((hit_bytes - off) / (lists * 16), (size_t)1 << 20);
+    if (slot_dst) {  // dense: keys go straight to their places
+        hipLaunchKernelGGL((scan_coarse64s_kernel<SC_METRIC_L2, true, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
+        return;
+    }
     hipLaunchKernelGGL((scan_coarse64s_kernel<SC_METRIC_L2, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
     hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, count, surv, cap);
 }
@@ -1519,6 +1553,14 @@ static void launch_rerank(const float* X, const float* xnorm, int ld, const floa
                        qres, overflow, k, row_base, perm, out_dist, out_rows, flags, kp, ekeys);
     hipLaunchKernelGGL(scan_finalize_kernel<METRIC>, dim3((unsigned)Q), dim3(256), 0, s, ekeys, kp, qnorm, thr, bits, qres, overflow, ld, k, row_base, out_dist,
                        out_rows, flags);
+}
+
+// exact L2 keys of cand [Q][kp] (the first ncand[q] slots of query q) -> ekeys [Q][kp]; nothing else (no sort, no certificate)
+void sc_launch_scan_rerank_keys_l2(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
+                                   const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s) {
+    hipLaunchKernelGGL((scan_rerank_kernel<SC_METRIC_L2, true>), dim3((unsigned)Q, (unsigned)(kp / KPRIME)), dim3(KPRIME), 0, s, X, xnorm, ld, Qp, qnorm, cand,
+                       (const float*)nullptr, (const unsigned*)nullptr, (const float*)nullptr, (const int*)nullptr, 0, (int64_t)0, perm, (float*)nullptr, (int64_t*)nullptr,
+                       (int*)nullptr, kp, ekeys, ncand);
 }
 
 // kp = KPRIME: one fused kernel; kp = KPRIME8 (int8 stage): blocks of 128 candidates re-scored into ekeys [Q][kp], then sorted

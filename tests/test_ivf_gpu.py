@@ -394,19 +394,25 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist)
             d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
             _native.diag_set_option("coarse_workgroups", wgs)
             ix.set_search_mode("ivf_coarse")
-            d5, r5 = ix.search(Q, k=k, nprobe=nprobe)
-            st = ix.last_search_stats()
-            assert st["path"] == "ivf_coarse", st
-            assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (dim, nq, k, nprobe, st)
-            assert st["uncertified"] <= max(2, nq // 3), st  # the certificate holds for the bulk of a clustered batch
+            for cap in (-1, 8):  # 8: a refine step that takes on 8 rows per query -- most queries go to the exact re-probe
+                _native.diag_set_option("ivf_refine_cap", cap)
+                d5, r5 = ix.search(Q, k=k, nprobe=nprobe)
+                st = ix.last_search_stats()
+                assert st["path"] == "ivf_coarse", st
+                assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (dim, nq, k, nprobe, cap, st)
+                if cap < 0:
+                    assert st["uncertified"] <= max(2, nq // 8), st  # bound and refine answers the bulk of a clustered batch itself
     finally:
         _native.diag_set_option("coarse_workgroups", 0)
+        _native.diag_set_option("ivf_refine_cap", -1)
         ix.close()
 
 
 def test_coarse_stage_survives_upserts_and_near_duplicates(rt):
-    """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow; 700 near-duplicates of
-    one row (more than the 512 candidates a query keeps, gaps far below any int8 bound) leave their queries uncertified, and the exact probe answers them: same bits again."""
+    """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow.  700 near-duplicates of
+    one row (gaps far below any int8 bound) all have lower bounds within reach of the k-th distance: the refine step re-scores them
+    all; with the step limited to 8 rows, and for 4500 duplicates (more than it takes on), the exact probe answers.  Same bits
+    every time."""
     X, centers = clustered(20_000, 128, 30, seed=51)
     rng = np.random.default_rng(52)
     ix = _native.Index(rt, 128, metric="L2", kind="IVF_FLAT", nlist=32)
@@ -416,11 +422,30 @@ def test_coarse_stage_survives_upserts_and_near_duplicates(rt):
     ix.add(dup)
     ix.overwrite(rng.standard_normal((2, 128)).astype(np.float32), np.array([7, 19_000], np.int64))
     Q = np.concatenate([dup[:20], (centers[rng.integers(0, 30, size=80)] + 0.4 * rng.standard_normal((80, 128))).astype(np.float32)])
-    ix.set_search_mode("ivf_listmajor")
-    d4, r4 = ix.search(Q, k=10, nprobe=8)
-    ix.set_search_mode("ivf_coarse")
-    d5, r5 = ix.search(Q, k=10, nprobe=8)
-    st = ix.last_search_stats()
-    assert st["path"] == "ivf_coarse" and st["uncertified"] >= 1, st
-    assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5))
-    ix.close()
+    try:
+        ix.set_search_mode("ivf_listmajor")
+        d4, r4 = ix.search(Q, k=10, nprobe=8)
+        ix.set_search_mode("ivf_coarse")
+        d6, r6 = ix.search(Q, k=10, nprobe=8)
+        st1 = ix.last_search_stats()
+        assert st1["path"] == "ivf_coarse" and st1["uncertified"] == 0, st1
+        assert np.array_equal(r4, r6) and np.array_equal(bits(d4), bits(d6))
+        _native.diag_set_option("ivf_refine_cap", 8)
+        d5, r5 = ix.search(Q, k=10, nprobe=8)
+        st0 = ix.last_search_stats()
+        assert st0["path"] == "ivf_coarse" and st0["uncertified"] >= 20, st0
+        assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5))
+        _native.diag_set_option("ivf_refine_cap", -1)
+        # more near-duplicates than the refine step takes on: those queries are probed exactly
+        dup2 = (X[123][None, :] + 1e-4 * rng.standard_normal((3800, 128))).astype(np.float32)
+        ix.add(dup2)
+        ix.set_search_mode("ivf_listmajor")
+        d7, r7 = ix.search(Q, k=10, nprobe=8)
+        ix.set_search_mode("ivf_coarse")
+        d8, r8 = ix.search(Q, k=10, nprobe=8)
+        st2 = ix.last_search_stats()
+        assert st2["path"] == "ivf_coarse" and st2["uncertified"] >= 20, st2
+        assert np.array_equal(r7, r8) and np.array_equal(bits(d7), bits(d8))
+    finally:
+        _native.diag_set_option("ivf_refine_cap", -1)
+        ix.close()
