@@ -528,29 +528,30 @@ def bench_ivf(ctx, args) -> dict:
     rt.synchronize()
     t_train = time.perf_counter() - t0
     sizes = ix.ivf_info()["list_sizes"]
-    ix.set_search_mode("ivf_listmajor")
 
     def step():
         ix.search_dev(q.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nprobe)
 
-    for _ in range(max(1, args.warmup)):
-        step()
-    rt.set_profiling(True)
-    rt.profile_reset()
-    dt = timed(ctx, step, args.steps)
-    k_ms, k_n = rt.profile_read(0)
-    rt.set_profiling(False)
-    got = out_r.cpu().numpy()
-    recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(got.tolist(), truth.tolist())]))
-    pst = ix.last_probe_stats()
-    ix.set_search_mode("auto")
-    step()
-    rt.synchronize()
-    t0 = time.perf_counter()
-    step()
-    rt.synchronize()
-    t_auto = time.perf_counter() - t0
-    auto_path = ix.last_search_stats()["path"]
+    def leg(mode):
+        ix.set_search_mode(mode)
+        for _ in range(max(1, args.warmup)):
+            step()
+        rt.set_profiling(True)
+        rt.profile_reset()
+        dt = timed(ctx, step, args.steps)
+        k_ms, k_n = rt.profile_read(0)
+        m_ms, _ = rt.profile_read(1)
+        rt.set_profiling(False)
+        st = ix.last_search_stats()
+        return {"dt": dt, "k_ms": k_ms, "k_n": k_n, "m_ms": m_ms, "path": st["path"], "uncertified": st["uncertified"], "pst": ix.last_probe_stats(),
+                "ids": out_r.cpu().numpy().copy(), "dist": out_d.cpu().numpy().copy()}
+
+    # the product's own choice ("auto": list-major probing behind the int8 coarse stage for such a batch) is the timed step;
+    # the exact f32 list-major probe is timed beside it and must return the same bits
+    auto = leg("auto")
+    exact = leg("ivf_listmajor")
+    same = bool(np.array_equal(auto["ids"], exact["ids"]) and np.array_equal(auto["dist"].view(np.uint32), exact["dist"].view(np.uint32)))
+    recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(auto["ids"].tolist(), truth.tolist())]))
     ix.set_search_mode("ivf")
     ix.search_dev(q.data_ptr(), 1, k, out_d.data_ptr(), out_r.data_ptr(), nprobe=nprobe)
     rt.synchronize()
@@ -559,24 +560,40 @@ def bench_ivf(ctx, args) -> dict:
     rt.synchronize()
     t_one = time.perf_counter() - t0
     ix.close()
-    step_s = dt / args.steps
+    step_s = auto["dt"] / args.steps
     ld = (dim + 63) // 64 * 64
-    streamed, unique = pst["streamed_rows"] * ld * 4, pst["unique_rows"] * ld * 4
-    kern_s = (k_ms / args.steps) * 1e-3 if k_n else None
-    return {"value": Q / step_s, "unit": "queries/s", "ms_per_step": 1e3 * step_s, "recall_at_10": recall, "path": "ivf_listmajor",
+    ld8 = (ld + 127) // 128 * 128
+    pst = auto["pst"]
+    coarse = auto["path"] == "ivf_coarse"
+    row_bytes = ld8 if coarse else ld * 4  # what the scan kernels of the timed path read per row
+    streamed, unique = pst["streamed_rows"] * row_bytes, pst["unique_rows"] * row_bytes
+    unique_f32 = pst["unique_rows"] * ld * 4
+    kern_s = (auto["k_ms"] / args.steps) * 1e-3 if auto["k_n"] else None
+    ex_s = exact["dt"] / args.steps
+    ex_kern_s = (exact["k_ms"] / args.steps) * 1e-3 if exact["k_n"] else None
+    ex_unique = exact["pst"]["unique_rows"] * ld * 4
+    return {"value": Q / step_s, "unit": "queries/s", "ms_per_step": 1e3 * step_s, "recall_at_10": recall, "path": auto["path"],
+            "uncertified": auto["uncertified"], "same_bits_as_exact_listmajor": same,
             "workload": f"IVF_FLAT nlist={nlist} nprobe={nprobe}, {rows} x {dim} f32 rows (clustered synthetic, device generated), batch-{Q} queries, L2 top-{k}",
             "train_s": t_train, "list_size_min_median_max": [int(sizes.min()), int(np.median(sizes)), int(sizes.max())],
-            "roofline": {"bound": "hbm", "kernel": "scan_listgemm_kernel (lists wanted by > 16 queries, 32 / 64 per group) + scan_exact_kernel (segment mode, <= 16 per group)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "scan_coarse64s_kernel<L2, GROUPED> (int8 lists centred on their centroids, 64 (query, list) slots per group; phase A dense, phase B against the exact bound) + the quantizer's scan_exact_kernel"
+                                   if coarse else "scan_listgemm_kernel + scan_exact_kernel (segment mode)",
+                         "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": unique / kern_s / 1e9 if kern_s else None, "frac": unique / kern_s / 1e9 / HBM_PEAK_GBS if kern_s else None,
                          "algorithmic_bytes_per_step": unique, "streamed_bytes_per_step": streamed, "groups": pst["groups"],
-                         "kernel_ms_per_step": k_ms / args.steps if k_n else None,
-                         "f32_mfma_view": {"algorithmic_flops_per_step": 2.0 * Q * nprobe * (rows / nlist) * dim, "peak_tflops": 157.3,
-                                           "achieved_tflops": 2.0 * Q * nprobe * (rows / nlist) * dim / kern_s / 1e12 if kern_s else None,
-                                           "note": "exact f32 scores of every (query, probed row) pair on v_mfma_f32_16x16x4_f32: the roof that binds once a list is streamed once per 64 queries"},
-                         "note": "algorithmic = bytes of the DISTINCT probed lists (SURVEY 8d config 5); streamed = what the kernels read "
-                                 "(a list is streamed once per group of up to 64 queries that probe it, 16 for the remainders)"},
+                         "kernel_ms_per_step": auto["k_ms"] / args.steps if auto["k_n"] else None,
+                         "select_rerank_ms_per_step": auto["m_ms"] / args.steps,
+                         "algorithmic_f32_gbs": unique_f32 / step_s / 1e9,
+                         "note": "algorithmic = bytes of the DISTINCT probed lists in the form the timed path streams them (int8 shadow: 1 B per padded element; "
+                                 "SURVEY 8d's f32 figure is algorithmic_f32_gbs, whole step, NOT a memory rate); streamed = what the scan kernels read "
+                                 "(a list is streamed once per group of up to 64 queries that probe it; re-reads mostly hit L2 / MALL)"},
+            "exact_listmajor": {"ms_per_batch": 1e3 * ex_s, "qps": Q / ex_s, "path": exact["path"], "kernel_ms_per_step": exact["k_ms"] / args.steps if exact["k_n"] else None,
+                                "hbm_frac_f32_lists": ex_unique / ex_kern_s / 1e9 / HBM_PEAK_GBS if ex_kern_s else None,
+                                "f32_mfma_view": {"algorithmic_flops_per_step": 2.0 * Q * nprobe * (rows / nlist) * dim, "peak_tflops": 157.3,
+                                                  "achieved_tflops": 2.0 * Q * nprobe * (rows / nlist) * dim / ex_kern_s / 1e12 if ex_kern_s else None,
+                                                  "note": "exact f32 scores of every (query, probed row) pair on v_mfma_f32_16x16x4_f32"}},
             "exhaustive": {"ms_per_batch": 1e3 * t_bf, "qps": Q / t_bf, "path": bf_stats["path"], "uncertified": bf_stats["uncertified"]},
-            "auto_planner": {"path": auto_path, "ms_per_batch": 1e3 * t_auto}, "single_query_ms": 1e3 * t_one}
+            "single_query_ms": 1e3 * t_one}
 
 
 # ------------------------------------------------------------------------------------------- main
