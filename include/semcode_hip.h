@@ -198,7 +198,8 @@ sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t
  * of the persistent coarse-scan kernel (0 = one workgroup per CU), so that tests can make a few workgroups walk many tiles;
  * "coarse_persistent": 0 = one workgroup per tile instead; "gemm_pp": main loop of the 256-tile GEMMs (-1 default, 0 = one barrier
  * per K-tile, 2..5 = ping-pong with that many half-tiles in flight); "ivf_refresh_nomem": 1 = the re-layout of a trained IVF index
- * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "ivf_refine_cap":
+ * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "collect_pass": 0 = queries a
+ * coarse stage cannot certify go straight to the next stage (no collect pass); "ivf_refine_cap":
  * rows per query the IVF coarse stage's refine step takes on (-1 = default 4096; a small value sends queries to the exact re-probe). */
 sc_status sc_diag_set_option(const char* name, int32_t value);
 /* qkv [B*S, 3*heads*64] rows = [Q | K | V]; lens [B]; out [B*S, heads*64] = softmax(QK^T/8 + mask) V. */
@@ -299,6 +300,10 @@ sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits);
 /* After a batched search: the stage it started on (8 / 16) and how many queries the int8 stage handed to the bf16 stage
  * (sc_index_last_search_stats' `uncertified` counts the queries that ended in the exact scan). */
 sc_status sc_index_last_coarse_stats(sc_index* ix, int32_t* first_stage_bits, int32_t* handed_to_bf16);
+/* Collect passes of the last batched search: queries whose certificate failed at a stage are given a second pass at the same
+ * precision with a fixed threshold (k-th exact score found + the coarse error bound) whose survivors are ALL re-scored exactly;
+ * `tried` = such queries (summed over the stages), `resolved` = those it answered (the rest went on to the next stage). */
+sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, int32_t* resolved);
 
 /* After an IVF probe search: rows of the DISTINCT lists the batch probed (`unique_rows`: the algorithmic bytes of SURVEY.md 8d
  * config 5 = unique_rows * ld * 4), rows the scan kernel streamed (`streamed_rows`: list-major probing streams a list once per

@@ -26,7 +26,7 @@ for name, ncl, spread in (("gaussian", 0, 0.0), ("clustered 4096 x 0.5", 4096, 0
     qsrc.close()
     od = torch.empty((Q, k), dtype=torch.float32, device=dev)
     orow = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    for stage in (0, 16):
+    for stage in (0, 8, 16):
         ix.set_coarse_stage(stage)
         for _ in range(2):
             ix.search_dev(q.data_ptr(), Q, k, od.data_ptr(), orow.data_ptr())
@@ -37,7 +37,7 @@ for name, ncl, spread in (("gaussian", 0, 0.0), ("clustered 4096 x 0.5", 4096, 0
         rt.synchronize()
         dt = (time.perf_counter() - t0) / 3
         st = ix.last_search_stats()
-        print(f"{name:22s} first stage {'int8' if st.get('coarse_bits') == 8 else 'bf16'}: {dt * 1e3:8.2f} ms / batch   handed to bf16 {st.get('handed_to_bf16', 0):4d}   "
-              f"uncertified (exact scan) {st['uncertified']:4d}", flush=True)
+        print(f"{name:22s} stage setting {stage:2d}, first stage {'int8' if st.get('coarse_bits') == 8 else 'bf16'}: {dt * 1e3:8.2f} ms / batch   collect pass {st.get('collect_resolved', 0):4d} of "
+              f"{st.get('collect_tried', 0):4d}   handed to bf16 {st.get('handed_to_bf16', 0):4d}   uncertified (exact scan) {st['uncertified']:4d}", flush=True)
     ix.close()
 rt.close()

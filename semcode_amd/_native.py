@@ -102,6 +102,7 @@ SIGNATURES = {
     "sc_index_last_search_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_set_coarse_stage": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_coarse_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_index_last_collect_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sc_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -369,13 +370,16 @@ class Index:
 
     def last_search_stats(self) -> dict:
         """path; `uncertified` = queries that ended in the exact scan; for the batched path also the stage it started on
-        (`coarse_bits` 8 / 16) and how many queries the int8 stage handed to the bf16 stage (`handed_to_bf16`)."""
+        (`coarse_bits` 8 / 16), how many queries the int8 stage handed to the bf16 stage (`handed_to_bf16`), and how many
+        queries went through a collect pass after a failed certificate / were answered by it (`collect_tried`, `collect_resolved`)."""
         path, unc, bits, handed = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
         _check(lib().sc_index_last_coarse_stats(self.handle, C.byref(bits), C.byref(handed)))
         out = {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor", 5: "ivf_coarse"}[path.value], "uncertified": unc.value}
         if path.value == 2:
-            out.update(coarse_bits=bits.value, handed_to_bf16=handed.value)
+            tried, resolved = C.c_int32(), C.c_int32()
+            _check(lib().sc_index_last_collect_stats(self.handle, C.byref(tried), C.byref(resolved)))
+            out.update(coarse_bits=bits.value, handed_to_bf16=handed.value, collect_tried=tried.value, collect_resolved=resolved.value)
         return out
 
     def search_sharded(self, comm: "Comm", queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:

@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void ivf_candidates_kernel(const uint64_t* __r
 }
 
 // exact keys of the kpa + ncand[q] re-scored rows -> the k best, in order (flagged queries are left to the exact probe)
-__global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(const uint64_t* __restrict__ ekeysA, int kpa, const uint64_t* __restrict__ ekeys, const int* __restrict__ ncand,
-                                                                   const int* __restrict__ flags, int k, int64_t row_base, float* __restrict__ out_dist,
-                                                                   int64_t* __restrict__ out_rows) {
+__global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(int metric, const uint64_t* __restrict__ ekeysA, int kpa, const uint64_t* __restrict__ ekeys,
+                                                                   const int* __restrict__ ncand, const int* __restrict__ flags, int k, int64_t row_base,
+                                                                   float* __restrict__ out_dist, int64_t* __restrict__ out_rows) {
     __shared__ uint64_t keys[IVFW_CAP + 512];
     __shared__ uint64_t wmin[4];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(const uint64_t
         if (tid == 0) {
             const size_t o = (size_t)q * k + j;
             if (b != SC_KEY_MAX) {
-                out_dist[o] = sc_key_score(SC_METRIC_L2, b);
+                out_dist[o] = sc_key_score(metric, b);
                 out_rows[o] = row_base + (int64_t)(uint32_t)b;
             } else {
-                out_dist[o] = __builtin_inff();
+                out_dist[o] = (metric == SC_METRIC_L2) ? __builtin_inff() : -__builtin_inff();
                 out_rows[o] = -1;
             }
         }
@@ -336,5 +336,11 @@ void sc_launch_ivf_candidates(const uint64_t* survA, const unsigned* cntA, const
 }
 void sc_launch_ivf_refine_finalize(const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist,
                                    int64_t* out_rows, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
+    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, (int)SC_METRIC_L2, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
+}
+// the same for the exhaustive path's collect pass (scan_batched.hip): ekeys [Q][sc_ivf_widen_cap()], any metric, no pre-scored block
+void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
+                               int Q, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, (const uint64_t*)nullptr, 0, ekeys, ncand, flags, k, row_base, out_dist,
+                       out_rows);
 }

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "sc_internal.h"
@@ -478,6 +479,9 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     ix->shadow_rows = 0;
     ix->shadow8_rows = 0;
     ix->i8_off = false;
+    ix->i8_sticky = false;
+    ix->cost_i8_first = 0.0;
+    ix->collect_off8 = ix->collect_off16 = false;
     return SC_OK;
 }
 
@@ -498,6 +502,9 @@ extern "C" sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, 
     ix->shadow_rows = 0;
     ix->shadow8_rows = 0;
     ix->i8_off = false;
+    ix->i8_sticky = false;
+    ix->cost_i8_first = 0.0;
+    ix->collect_off8 = ix->collect_off16 = false;
     return SC_OK;
 }
 
@@ -666,6 +673,65 @@ static int coarse_env() {
     return v;
 }
 
+static int g_collect_pass = 1;  // sc_diag_set_option("collect_pass", 0): uncertified queries go straight to the next stage (tests, A/B)
+void sc_set_collect_pass(int v) { g_collect_pass = v; }
+
+// The collect pass (scan_batched.hip, "the collect pass"): the sub-batch `fq` [R][dim] of queries a stage could not certify, with
+// that stage's results in fd / fr [R][k] (fd's k-th column bounds the k-th score).  Resolved queries get their final results
+// written into fd / fr; `left` receives the sub-batch positions of those that still need the next stage (more than BATCH_CAP rows
+// within the bound, or no bound).  Uses the same scratch as the stage that called it (which is done with it).
+static sc_status search_collect_locked(sc_index* ix, const float* fq, int R, int k, float* fd, int64_t* fr, bool i8, std::vector<int>& left) {
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    const int metric = (int)ix->metric, ld = ix->ld, ld8 = ld8_of(ix);
+    const int Qpad = (i8 || R > 128) ? (R + 255) / 256 * 256 : 128;
+    static_assert(BATCH_CAP == 4096, "the refine kernels' candidate stride (sc_ivf_widen_cap) is the survivor cap");
+    if (sc_ivf_widen_cap() != BATCH_CAP) return sc_fail(SC_ERR_STATE, "collect pass: candidate stride mismatch");
+    sc_status st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)R * ld * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)R * 4);
+    if (st) return st;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_qres = carve((size_t)R * 4), o_amax = carve(16);
+    const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
+                 o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)R * 4), o_ovf = carve((size_t)R * 4), o_flag = carve((size_t)R * 4), o_nc = carve((size_t)R * 4),
+                 o_surv = carve((size_t)R * BATCH_CAP * 8), o_ek = carve((size_t)R * BATCH_CAP * 8);
+    const size_t hit_bytes = (i8 && R <= 64) ? (size_t)2048 * (4 + 1024 * 16) + 256 : 0;
+    const size_t o_hits = carve(hit_bytes ? hit_bytes : 16);
+    st = sc_grow(ix, &ix->bscratch, &ix->bscratch_cap, off);
+    if (st) return st;
+    char* b = (char*)ix->bscratch;
+    void* Qb = b + o_qb;
+    float *qres = (float*)(b + o_qres), *qscale = (float*)(b + o_qs), *thr = (float*)(b + o_thr), *tf = (float*)(b + o_tf);
+    unsigned* cnt = (unsigned*)(b + o_cnt);
+    int *ovf = (int*)(b + o_ovf), *flags = (int*)(b + o_flag), *ncand = (int*)(b + o_nc);
+    uint64_t *surv = (uint64_t*)(b + o_surv), *ekeys = (uint64_t*)(b + o_ek);
+    sc_launch_ingest_rows(fq, nullptr, 0, R, ix->dim, ix->qpad, ld, ix->qnorm, s);
+    if (i8) sc_launch_query_i8(ix->qpad, R, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
+    else sc_launch_query_bf16(ix->qpad, R, Qpad, ld, Qb, qres, s);
+    sc_launch_scan_batched_init(thr, tf, Qpad, nullptr, cnt, ovf, R, 0, s);
+    sc_launch_scan_collect_bound(metric, fd, k, ix->qnorm, qres, i8 ? ix->xnorm_max8 : ix->xnorm_max, ld, thr, tf, flags, R, s);
+    hipEvent_t e0, e1;
+    sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+    if (i8) sc_launch_scan_coarse(metric, ix->Xq, ix->xnorm, 0, ix->n, ld8, Qb, ix->qnorm, R, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, true, ix->xscale, qscale, false, hit_bytes ? (void*)(b + o_hits) : nullptr, hit_bytes);
+    else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, 0, ix->n, ld, Qb, ix->qnorm, R, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, false, nullptr, nullptr, false);
+    sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+    sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+    sc_launch_scan_collect_counts(cnt, BATCH_CAP, ncand, flags, R, s);
+    sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, surv, ncand, BATCH_CAP, ix->perm, ekeys, R, s);
+    sc_launch_refine_finalize(metric, ekeys, ncand, flags, k, ix->row_base, fd, fr, R, s);
+    sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+    SC_HIP(hipGetLastError());
+    std::vector<int> hflags(R);
+    SC_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+    SC_HIP(hipStreamSynchronize(s));
+    left.clear();
+    for (int j = 0; j < R; ++j)
+        if (hflags[j]) left.push_back(j);
+    return SC_OK;
+}
+
 static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows, bool i8, int depth,
                                              int Q_top) {
     sc_runtime* rt = ix->rt;
@@ -731,14 +797,44 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     std::vector<int> redo;
     for (int i = 0; i < Q; ++i)
         if (hflags[i]) redo.push_back(i);
-    const int R = (int)redo.size();
-    const bool to_bf16 = i8 && coarse_pin(ix) != 8 && R > 16;  // a handful of queries is one pass of the exact scan: not worth a bf16 shadow
+    int R = (int)redo.size();
     if (i8) {
-        ix->last_uncert_i8 = R;
         // most of a real batch uncertified: this corpus does not quantise well enough (tight clusters, outlier dimensions) --
         // later searches start at the bf16 stage until the rows are replaced wholesale
-        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8) ix->i8_off = true;
+        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8 && !ix->i8_sticky) ix->i8_off = true;
     }
+    // second chance at this stage's precision: the collect pass (every row within the coarse error of the k-th exact score found)
+    bool& collect_off = i8 ? ix->collect_off8 : ix->collect_off16;
+    if (R > 0 && g_collect_pass && !collect_off) {
+        void** buf = depth == 0 ? &ix->fb : &ix->fb2;
+        size_t* cap = depth == 0 ? &ix->fb_cap : &ix->fb2_cap;
+        const size_t qb = ((size_t)R * ix->dim * 4 + 255) & ~(size_t)255, db = ((size_t)R * k * 4 + 255) & ~(size_t)255, rb = ((size_t)R * k * 8 + 255) & ~(size_t)255;
+        st = sc_grow(ix, buf, cap, qb + db + rb + (size_t)R * 4);
+        if (st) return st;
+        float* fq = (float*)*buf;
+        float* fd = (float*)((char*)*buf + qb);
+        int64_t* fr = (int64_t*)((char*)*buf + qb + db);
+        int32_t* fidx = (int32_t*)((char*)*buf + qb + db + rb);
+        SC_HIP(hipMemcpyAsync(fidx, redo.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+        sc_launch_copy_rows_indexed(q_dev, fq, fidx, R, (size_t)ix->dim * 4, false, s);
+        sc_launch_copy_rows_indexed(out_dist, fd, fidx, R, (size_t)k * 4, false, s);  // the failed pass's results: their k-th score is the bound
+        sc_launch_copy_rows_indexed(out_rows, fr, fidx, R, (size_t)k * 8, false, s);
+        std::vector<int> left;
+        st = search_collect_locked(ix, fq, R, k, fd, fr, i8, left);
+        if (st) return st;
+        sc_launch_copy_rows_indexed(fd, out_dist, fidx, R, (size_t)k * 4, true, s);
+        sc_launch_copy_rows_indexed(fr, out_rows, fidx, R, (size_t)k * 8, true, s);
+        SC_HIP(hipStreamSynchronize(s));
+        ix->last_collect_tried += R;
+        ix->last_collect_resolved += R - (int)left.size();
+        if (R >= 32 && (int)left.size() * 2 > R) collect_off = true;
+        std::vector<int> still;
+        for (int j : left) still.push_back(redo[(size_t)j]);
+        redo.swap(still);
+        R = (int)redo.size();
+    }
+    if (i8) ix->last_uncert_i8 = R;
+    const bool to_bf16 = i8 && coarse_pin(ix) != 8 && R > 16;  // a handful of queries is one pass of the exact scan: not worth a bf16 shadow
     if (!to_bf16) {  // what is left goes to the exact scan
         ix->last_uncertified = R;
         ix->uncert_frac = (double)R / (double)Q_top;
@@ -784,7 +880,27 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
     ix->last_uncertified = 0;
-    return search_batched_stage_locked(ix, q_dev, Q, k, out_dist, out_rows, i8, 0, Q);
+    ix->last_collect_tried = ix->last_collect_resolved = 0;
+    // Which stage to START at on a corpus the int8 certificate fails on is settled by the clock: the int8 stage switches itself off
+    // when it fails for a quarter of a batch (above); the cost per query of that batch (int8 pass + its collect pass + whatever went
+    // on) is remembered, and if the bf16-first batch that follows costs more (tight clusters: bf16 needs its collect pass too, at
+    // twice the bytes and half the MFMA rate), the int8 stage is switched back on for good.  10M x 768, 4096 clusters of spread
+    // 0.1: 26.2 ms bf16-first, 16.9 ms int8-first (profiles/r3z_clustered_probe.log).
+    const bool was_off = ix->i8_off;
+    const auto t0 = std::chrono::steady_clock::now();
+    const sc_status st = search_batched_stage_locked(ix, q_dev, Q, k, out_dist, out_rows, i8, 0, Q);
+    if (st == SC_OK && env == 0 && Q >= 64 && !ix->i8_sticky) {
+        const double per_q = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / Q;
+        if (i8 && !was_off && ix->i8_off) ix->cost_i8_first = per_q;  // the batch that switched the int8 stage off
+        else if (!i8 && was_off && ix->cost_i8_first > 0.0 && ix->last_collect_tried * 4 > Q) {
+            if (ix->cost_i8_first < 0.85 * per_q) {
+                ix->i8_off = false;
+                ix->i8_sticky = true;
+            }
+            ix->cost_i8_first = 0.0;  // decided either way
+        }
+    }
+    return st;
 }
 
 sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, float* out_dist, int64_t* out_rows) {
@@ -842,7 +958,8 @@ extern "C" sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits) {
     if (!ix || (bits != 0 && bits != 8 && bits != 16)) return sc_fail(SC_ERR_INVALID, "sc_index_set_coarse_stage: bits must be 0 (auto), 8 or 16");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->coarse_mode = bits;
-    if (bits == 0) ix->i8_off = false;
+    if (bits == 0) { ix->i8_off = false; ix->i8_sticky = false; ix->cost_i8_first = 0.0; }
+    ix->collect_off8 = ix->collect_off16 = false;
     return SC_OK;
 }
 
@@ -851,6 +968,14 @@ extern "C" sc_status sc_index_last_coarse_stats(sc_index* ix, int32_t* first_sta
     std::lock_guard<std::mutex> g(ix->mu);
     if (first_stage_bits) *first_stage_bits = ix->last_coarse_bits;
     if (handed_to_bf16) *handed_to_bf16 = ix->last_uncert_i8;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, int32_t* resolved) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (tried) *tried = ix->last_collect_tried;
+    if (resolved) *resolved = ix->last_collect_resolved;
     return SC_OK;
 }
 

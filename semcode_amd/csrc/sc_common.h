@@ -179,6 +179,14 @@ void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const voi
                           const int32_t* slot_dst = nullptr);  // non-null: dense phase (every row survives; count[] preset by the caller)
 void sc_launch_scan_rerank_keys_l2(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
                                    const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s);
+void sc_launch_scan_rerank_keys(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
+                                const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s);
+// the collect pass of the exhaustive batched path (scan_batched.hip): thresholds from the k-th exact score of the failed pass; survivor counts -> candidate counts
+void sc_launch_scan_collect_bound(int metric, const float* prev_dist, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
+                                  float* thr_fast, int* flags, int Q, hipStream_t s);
+void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, int* flags, int Q, hipStream_t s);
+void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
+                               int Q, hipStream_t s);
 int sc_ivf_widen_cap(void);
 void sc_launch_ivf_bound(const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s);
 void sc_launch_ivf_candidates(const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,

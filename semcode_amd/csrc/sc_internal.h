@@ -73,6 +73,10 @@ struct sc_index {
     bool i8_off = false;                          // the int8 certificate failed for most of a batch on this corpus: use the bf16 stage
     int last_coarse_bits = 0;                     // 8 / 16: coarse stage of the last batched search
     int last_uncert_i8 = 0;                       // queries the int8 stage handed on to the bf16 stage
+    bool i8_sticky = false;                       // ... but the bf16-first batch that followed cost more: int8 first from now on (search_batched_locked)
+    double cost_i8_first = 0.0;                   // seconds per query of the batch that switched the int8 stage off (0 = none pending)
+    bool collect_off8 = false, collect_off16 = false;  // the collect pass of that stage resolved less than half of a sub-batch: skip it on this corpus
+    int last_collect_tried = 0, last_collect_resolved = 0;  // queries of the last batched search that went through a collect pass / that it answered
     void* bscratch = nullptr; size_t bscratch_cap = 0;
     void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results) of the first stage's uncertified queries
     void* fb2 = nullptr;     size_t fb2_cap = 0;  // the same for the second stage (int8 -> bf16 -> exact)

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(SEL_THREADS) void scan_select_kernel(uint64_t* __re
 // over the corpus, qres = |q - qc|^2).  The int8 dot itself is exact; its scaling to f32 rounds three times, which the
 // ld * 1.2e-7 term (sized for the f32 accumulation of the bf16 stage) covers many times over.
 template <int METRIC>
-static __device__ __forceinline__ bool certified(uint64_t kth_key, const unsigned* __restrict__ bits, float qnorm2, float qres2, int ld, float tau) {
+static __device__ __forceinline__ float certificate_eps(const unsigned* __restrict__ bits, float qnorm2, float qres2, int ld) {
     const float xmax = sqrtf(__builtin_bit_cast(float, bits[0]));
     const float xres = sqrtf(__builtin_bit_cast(float, bits[1]));
     const float qn = sqrtf(qnorm2);
@@ -740,10 +740,13 @@ static __device__ __forceinline__ bool certified(uint64_t kth_key, const unsigne
         const float relx = sqrtf(__builtin_bit_cast(float, bits[2]));
         eps = relx + (1.0f + relx) * (sqrtf(qres2) / fmaxf(qn, 1e-30f)) + (float)ld * 1.2e-7f * (1.0f + relx);
     } else eps = ddot;
-    eps = eps * 1.01f + 1e-6f;
+    return eps * 1.01f + 1e-6f;
+}
+template <int METRIC>
+static __device__ __forceinline__ bool certified(uint64_t kth_key, const unsigned* __restrict__ bits, float qnorm2, float qres2, int ld, float tau) {
     const float sc = sc_key_score(METRIC, kth_key);
     const float vk = (METRIC == SC_METRIC_L2) ? sc : -sc;
-    return vk + eps < tau;
+    return vk + certificate_eps<METRIC>(bits, qnorm2, qres2, ld) < tau;
 }
 // SPLIT (int8 stage, KPRIME8 candidates): blockIdx.y selects a block of 128 candidates, the exact keys go to ekeys [Q][kp] and
 // scan_finalize_kernel sorts them and evaluates the certificate.
@@ -889,6 +892,46 @@ __global__ __launch_bounds__(256) void scan_finalize_kernel(const uint64_t* __re
         }
         flags[q] = bad;
     }
+}
+
+// ---- the collect pass (second chance of a query whose certificate failed) ------------------------------------------------------------
+// The certificate compares the k-th exact score with the kp-th best COARSE score; it fails when more than kp rows are within the
+// coarse error of the k-th neighbour (clustered corpora: a whole cluster is).  The failed pass still leaves a true upper bound of
+// the k-th score: vk, the k-th exact score among its candidates.  A row can only belong to the result if its exact v-score is
+// <= vk, i.e. its coarse v-score <= vk + eps =: T.  The collect pass runs the same coarse kernel once more over all rows with the
+// FIXED threshold T (no selection, no shrinking), keeps every row that passes (up to BATCH_CAP per query), re-scores them all exactly
+// and takes the exact top-k: correct by construction -- no candidate count to exceed.  Only a query with more than BATCH_CAP rows
+// within T goes on to the next stage.  10M x 768 in 4096 clusters of spread 0.1: every query used to end in the exact scan
+// (347 ms per 1024-query batch, profiles/r3t_clustered_probe.log); see DESIGN.md section 4 for what it takes now.
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_collect_bound_kernel(const float* __restrict__ prev_dist, int k, const float* __restrict__ qnorm,
+                                                                  const float* __restrict__ qres, const unsigned* __restrict__ bits, int ld,
+                                                                  float* __restrict__ thr, float* __restrict__ thr_fast, int* __restrict__ flags, int Q) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    const float d = prev_dist[(size_t)q * k + (k - 1)];
+    const float vk = (METRIC == SC_METRIC_L2) ? d : -d;
+    const bool ok = fabsf(vk) < 3.0e38f;  // fewer than k candidates (+-inf) or NaN: nothing to bound with
+    float t = -__builtin_inff(), tf = -__builtin_inff();
+    if (ok) {
+        t = vk + certificate_eps<METRIC>(bits, qnorm[q], qres[q], ld);
+        const float slack = 1e-3f * fabsf(t) + 1e-6f;  // the fast test must pass whatever the precise one passes (scan_select_kernel)
+        const float qn = qnorm[q];
+        if (METRIC == SC_METRIC_L2) tf = (t - qn) + slack + 1e-3f * fabsf(qn);
+        else if (METRIC == SC_METRIC_COSINE) tf = (t + slack) * sqrtf(qn) + 1e-5f * sqrtf(qn);
+        else tf = t + slack;
+    }
+    thr[q] = t;
+    thr_fast[q] = tf;
+    flags[q] = ok ? 0 : 1;
+}
+__global__ __launch_bounds__(256) void scan_collect_counts_kernel(const unsigned* __restrict__ count, int cap, int* __restrict__ ncand, int* __restrict__ flags, int Q) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    const unsigned c = count[q];
+    const bool fits = c <= (unsigned)cap && !flags[q];
+    ncand[q] = fits ? (int)c : 0;
+    if (!fits) flags[q] = 1;
 }
 
 __global__ __launch_bounds__(256) void scan_batched_init_kernel(float* thr, float* thr_fast, int qpad, uint64_t* best, unsigned* count,
@@ -1555,12 +1598,33 @@ static void launch_rerank(const float* X, const float* xnorm, int ld, const floa
                        out_rows, flags);
 }
 
-// exact L2 keys of cand [Q][kp] (the first ncand[q] slots of query q) -> ekeys [Q][kp]; nothing else (no sort, no certificate)
-void sc_launch_scan_rerank_keys_l2(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
-                                   const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s) {
-    hipLaunchKernelGGL((scan_rerank_kernel<SC_METRIC_L2, true>), dim3((unsigned)Q, (unsigned)(kp / KPRIME)), dim3(KPRIME), 0, s, X, xnorm, ld, Qp, qnorm, cand,
+// exact keys of cand [Q][kp] (the first ncand[q] slots of query q) -> ekeys [Q][kp]; nothing else (no sort, no certificate)
+template <int METRIC>
+static void launch_rerank_keys(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
+                               const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s) {
+    hipLaunchKernelGGL((scan_rerank_kernel<METRIC, true>), dim3((unsigned)Q, (unsigned)(kp / KPRIME)), dim3(KPRIME), 0, s, X, xnorm, ld, Qp, qnorm, cand,
                        (const float*)nullptr, (const unsigned*)nullptr, (const float*)nullptr, (const int*)nullptr, 0, (int64_t)0, perm, (float*)nullptr, (int64_t*)nullptr,
                        (int*)nullptr, kp, ekeys, ncand);
+}
+void sc_launch_scan_rerank_keys(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
+                                const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s) {
+    if (metric == SC_METRIC_L2) launch_rerank_keys<SC_METRIC_L2>(X, xnorm, ld, Qp, qnorm, cand, ncand, kp, perm, ekeys, Q, s);
+    else if (metric == SC_METRIC_COSINE) launch_rerank_keys<SC_METRIC_COSINE>(X, xnorm, ld, Qp, qnorm, cand, ncand, kp, perm, ekeys, Q, s);
+    else launch_rerank_keys<SC_METRIC_IP>(X, xnorm, ld, Qp, qnorm, cand, ncand, kp, perm, ekeys, Q, s);
+}
+void sc_launch_scan_rerank_keys_l2(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
+                                   const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s) {
+    launch_rerank_keys<SC_METRIC_L2>(X, xnorm, ld, Qp, qnorm, cand, ncand, kp, perm, ekeys, Q, s);
+}
+void sc_launch_scan_collect_bound(int metric, const float* prev_dist, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
+                                  float* thr_fast, int* flags, int Q, hipStream_t s) {
+    const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_L2>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_COSINE>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
+    else hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_IP>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
+}
+void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, int* flags, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(scan_collect_counts_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, count, cap, ncand, flags, Q);
 }
 
 // kp = KPRIME: one fused kernel; kp = KPRIME8 (int8 stage): blocks of 128 candidates re-scored into ekeys [Q][kp], then sorted

@@ -54,7 +54,11 @@ def test_teardown_after_fallback_release_scratch_and_train():
         ix.add(base)
         Q = np.concatenate([base[5000:5001] + 1e-5, orc.synth(39, 96, seed=5)])
         ix.set_search_mode("batched")
-        d, r = ix.search(Q, k=10)
+        _native.diag_set_option("collect_pass", 0)  # (the collect pass would answer these queries: the sequence needs the exact fallback)
+        try:
+            d, r = ix.search(Q, k=10)
+        finally:
+            _native.diag_set_option("collect_pass", 1)
         st = ix.last_search_stats()
         assert st["path"] == "batched" and st["uncertified"] >= 1
         od, orow = orc.search(base, Q, 10, "L2")

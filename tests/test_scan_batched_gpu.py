@@ -166,14 +166,51 @@ def test_near_duplicates_defeat_the_certificate_but_not_the_result(rt, metric):
     ix = _native.Index(rt, 256, metric=metric)
     ix.add(X)
     ix.set_search_mode("batched")
-    d, r = ix.search(Q, k=16)
-    st = ix.last_search_stats()
-    assert st["path"] == "batched" and st["uncertified"] >= 1
     od, orow = orc.search(X, Q, 16, metric)
-    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    try:
+        # the collect pass (every row within the coarse error of the k-th exact score, re-scored exactly) answers the query ...
+        d, r = ix.search(Q, k=16)
+        st = ix.last_search_stats()
+        assert st["path"] == "batched" and st["collect_resolved"] >= 1 and st["uncertified"] == 0, st
+        assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+        # ... and without it the exact scan does
+        _native.diag_set_option("collect_pass", 0)
+        d, r = ix.search(Q, k=16)
+        st = ix.last_search_stats()
+        assert st["path"] == "batched" and st["uncertified"] >= 1 and st["collect_tried"] == 0, st
+        assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od))
+    finally:
+        _native.diag_set_option("collect_pass", 1)
     ix.set_search_mode("exact")
     d2, r2 = ix.search(Q, k=16)
     assert np.array_equal(r2, r) and np.array_equal(bits(d2), bits(d))
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["IP", "L2", "COSINE"])
+@pytest.mark.parametrize("stage", [8, 16])
+def test_collect_pass_answers_clustered_batches_and_hands_on_what_it_cannot_hold(rt, metric, stage):
+    """Tight clusters: hundreds of rows lie within the coarse error of the k-th neighbour, far more than the candidates a stage keeps, so
+    its certificate fails for most of the batch.  The collect pass re-scores every row within the bound and answers them; a query
+    sitting on 5000 near-duplicates (more than the pass keeps per query) goes on to the next stage.  Bit-exact throughout."""
+    rng = np.random.default_rng(21)
+    ncl, per, dim = 12, 1500, 192
+    centers = 4.0 * rng.standard_normal((ncl, dim)).astype(np.float32)
+    X = (np.repeat(centers, per, axis=0) + 0.02 * rng.standard_normal((ncl * per, dim))).astype(np.float32)
+    X = np.concatenate([X, (X[7][None, :] + 1e-5 * rng.standard_normal((5000, dim))).astype(np.float32)])
+    Q = (centers[rng.integers(0, ncl, size=47)] + 0.02 * rng.standard_normal((47, dim))).astype(np.float32)
+    Q = np.concatenate([Q, X[7:8] + 1e-6])
+    od, orow = orc.search(X, Q, 10, metric)
+    ix = _native.Index(rt, dim, metric=metric)
+    ix.add(X)
+    ix.set_search_mode("batched")
+    ix.set_coarse_stage(stage)
+    d, r = ix.search(Q, k=10)
+    st = ix.last_search_stats()
+    assert st["path"] == "batched" and st["coarse_bits"] == stage, st
+    assert np.array_equal(r, orow) and np.array_equal(bits(d), bits(od)), st
+    assert st["collect_tried"] >= 24 and st["collect_resolved"] >= st["collect_tried"] - 8, st  # the batch needed it, and it answered
+    assert st["collect_resolved"] < st["collect_tried"] or st["uncertified"] == 0, st
     ix.close()
 
 
