@@ -349,30 +349,35 @@ def bench_scan(ctx, args) -> dict:
                     exact_roof = cand
     ix.close()
 
-    # The same batch on a CLUSTERED corpus (4 096 Gaussian clusters, spread 0.5: what code embeddings look like more than i.i.d.
-    # rows do).  The certificate of the int8 stage does not hold there (per-row quantisation steps follow the cluster centres, not
-    # the spread), the index notices and starts at the bf16 stage, which certifies every query; reported: the steady-state batch.
+    # The same batch on CLUSTERED corpora (4 096 Gaussian clusters: what code embeddings look like more than i.i.d. rows do).
+    # Spread 0.5: the int8 certificate does not hold (more than 512 rows lie within the int8 error of the k-th neighbour); its collect
+    # pass answers the first batch, the index starts the next at the bf16 stage, which certifies every query, and stays there.
+    # Spread 0.1: the bf16 certificate fails as well; both stages answer through their collect pass and the clock picks int8-first.
+    # Reported: the steady-state batch (after three searches).
     clustered = None
     if not args.no_sweep and world == 1:
-        cx = _native.Index(rt, dim, metric=args.metric_type, kind="FLAT")
-        cx.fill_synthetic_clustered(rows, seed=0, nclusters=4096, spread=0.5)
-        qs = _native.Index(rt, dim, metric=args.metric_type)
-        qs.fill_synthetic_clustered(Q, seed=0, nclusters=4096, spread=0.5, first_row=rows + 12345)
-        qc = torch.from_numpy(qs.get_rows(0, Q)).to(dev)
-        qs.close()
-        cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr())
-        first = cx.last_search_stats()
-        cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr())
-        tc = timed(ctx, lambda: cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr()), max(2, args.steps // 2))
-        stc = cx.last_search_stats()
-        clustered = {"workload": f"{rows} x {dim} f32 rows in 4096 Gaussian clusters (spread 0.5), batch-{Q} queries drawn from the same clusters, {args.metric_type} top-{k}",
-                     "ms_per_step": 1e3 * tc / max(2, args.steps // 2), "value": Q * max(2, args.steps // 2) / tc, "unit": "queries/s",
-                     "first_stage": "int8" if stc.get("coarse_bits", 16) == 8 else "bf16", "handed_to_bf16": stc.get("handed_to_bf16", 0),
-                     "uncertified": stc["uncertified"],
-                     "first_batch": {"first_stage": "int8" if first.get("coarse_bits", 16) == 8 else "bf16", "handed_to_bf16": first.get("handed_to_bf16", 0),
-                                     "uncertified": first["uncertified"]},
-                     "note": "tighter clusters (spread 0.1) defeat the bf16 certificate too and every query takes the exact scan (scripts/clustered_probe.py)"}
-        cx.close()
+        clustered = {}
+        for tag, spread in (("spread_0.5", 0.5), ("spread_0.1", 0.1)):
+            cx = _native.Index(rt, dim, metric=args.metric_type, kind="FLAT")
+            cx.fill_synthetic_clustered(rows, seed=0, nclusters=4096, spread=spread)
+            qs = _native.Index(rt, dim, metric=args.metric_type)
+            qs.fill_synthetic_clustered(Q, seed=0, nclusters=4096, spread=spread, first_row=rows + 12345)
+            qc = torch.from_numpy(qs.get_rows(0, Q)).to(dev)
+            qs.close()
+            cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr())
+            first = cx.last_search_stats()
+            for _ in range(2):
+                cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr())
+            nst = max(2, args.steps // 2)
+            tc = timed(ctx, lambda: cx.search_dev(qc.data_ptr(), Q, k, out_d.data_ptr(), out_r.data_ptr()), nst)
+            stc = cx.last_search_stats()
+            brief = lambda st: {"first_stage": "int8" if st.get("coarse_bits", 16) == 8 else "bf16", "collect_pass_resolved_of_tried": [st.get("collect_resolved", 0), st.get("collect_tried", 0)],
+                                "handed_to_bf16": st.get("handed_to_bf16", 0), "uncertified": st["uncertified"]}
+            clustered[tag] = {"workload": f"{rows} x {dim} f32 rows in 4096 Gaussian clusters (spread {spread}), batch-{Q} queries drawn from the same clusters, {args.metric_type} top-{k}",
+                              "ms_per_step": 1e3 * tc / nst, "value": Q * nst / tc, "unit": "queries/s", **brief(stc), "first_batch": brief(first)}
+            cx.close()
+        clustered["note"] = ("collect pass = second pass at the same precision with the fixed threshold (k-th exact score found + coarse error bound), every survivor re-scored "
+                             "exactly; before it, spread 0.1 sent every query to the exact scan: 347 ms per batch (profiles/r3t_clustered_probe.log)")
 
     stats = None
     alg_bytes = rows * dim * 4  # the f32 shard is read once per query batch (+ norms, negligible)
