@@ -270,19 +270,45 @@ __global__ __launch_bounds__(256) void scan_coarse_kernel(CoarseArgs a) {
 // Per-query thresholds / norms of the workgroup's 256 queries sit in LDS behind the pipeline buffers, and a
 // lane queues its (rare) hits in registers so that the global atomics that allocate list slots are issued
 // back to back and their latency is paid once per tile, not once per hit.
-#define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256], qscale[256], xscale[256]} in LDS
-#define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 6 * 256 * 4)
+#define COARSE_QLDS (4 * T_TILE_BYTES)  // byte offset of {thr_fast[256], thr[256], qnorm[256], xnorm[256], qscale[256], xscale[256], row bounds [256][2]} in LDS
+#define COARSE_LDS_BYTES (4 * T_TILE_BYTES + 8 * 256 * 4)
 // per-tile staging of the workgroup's 256 query thresholds / norms and the tile's 256 row norms (visible to everyone after
 // the main loop's barriers)
 // ROWS / QUERIES: which half of the staging a call does (the persistent kernel stages the query side only when its query tile
 // changes and feeds the row side from registers it loaded a tile earlier)
-template <bool I8 = false, bool ROWS = true, bool QUERIES = true>
+// int8 stage: the two per-row constants of the epilogue's prefilter.  The fast test t <= tf_q is  acc >= (base_r - tf_q) R_r  with
+// base_r = |x|^2 (L2) or 0, R_r = 1 / (c_r s_r s_q), c_r = 2 (L2), 1 (IP), 1/|x| (cosine) and ONE query scale s_q per batch; with the
+// loosest tf of a lane's 16 queries the integer bound of a row is  Ti = (int)(A_r - tfmax' B_r)  -- one FMA per row block in the
+// epilogue instead of a reciprocal, the slack arithmetic and the clamps, which every lane of every tile recomputed (8 waves x 8 row
+// blocks; the epilogue is issue bound: 2.1-3.4 us per tile, profiles/r3k_coarse_trace.log).  A_r already carries every slack of the
+// row side (4e-6 relative, 2 units for the bound's own rounding, 1 for the truncation), B_r > 0 always; rows beyond the phase's end
+// (scale 0) get a bound nothing passes.
+template <int METRIC>
+static __device__ __forceinline__ void coarse_row_bound(float xn, float sx, float sq0, float& A, float& B) {
+    if (!(sx > 0.f)) { A = 3.0e38f; B = 1.0e-30f; return; }
+    const float c = (METRIC == SC_METRIC_L2) ? 2.0f * sx : (METRIC == SC_METRIC_COSINE) ? sx / sqrtf(xn) : sx;
+    float R = __builtin_amdgcn_rcpf(c * sq0);
+    if (!(R < 3.0e38f)) R = 3.0e38f;   // (cosine, |x| = 0: c = inf -> R = 0 is fine; c = 0 cannot happen with sx > 0 and finite xn)
+    if (!(R > 1.0e-30f)) R = 1.0e-30f;
+    float base = (METRIC == SC_METRIC_L2) ? xn * R : 0.f;
+    if (!(fabsf(base) < 3.0e38f)) base = -3.0e38f;  // inf / NaN: let everything through to the precise test
+    A = base - fabsf(base) * 4e-6f - 3.0f;
+    B = R;
+}
+template <bool I8 = false, bool ROWS = true, bool QUERIES = true, int METRIC = SC_METRIC_L2>
 static __device__ __forceinline__ void coarse256_stage(const CoarseArgs& a, int64_t m0, int n0, char* smem, int tid) {
     float* q_tf = reinterpret_cast<float*>(smem + COARSE_QLDS);
     if (ROWS && tid >= 256) {
         const int64_t row = m0 + (tid - 256);
-        q_tf[768 + tid - 256] = row < a.row1 ? a.xnorm[row] : 1.0f;
-        if (I8) q_tf[1280 + tid - 256] = row < a.row1 ? a.xscale[row] : 0.0f;
+        const float xn = row < a.row1 ? a.xnorm[row] : 1.0f;
+        q_tf[768 + tid - 256] = xn;
+        if (I8) {
+            const float sx = row < a.row1 ? a.xscale[row] : 0.0f;
+            q_tf[1280 + tid - 256] = sx;
+            float A, B;
+            coarse_row_bound<METRIC>(xn, sx, a.qscale[0], A, B);
+            *reinterpret_cast<f32x2*>(q_tf + 1536 + 2 * (tid - 256)) = f32x2{A, B};
+        }
     }
     if (QUERIES && tid < 256) {
         const int q = n0 + tid;
@@ -330,7 +356,9 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     float tfmax = -__builtin_inff();  // loosest fast threshold among this lane's 16 queries
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) tfmax = fmaxf(fmaxf(tfmax, fmaxf(tf[ni][0], tf[ni][1])), fmaxf(tf[ni][2], tf[ni][3]));
-    const float sq0 = I8 ? sq[0][0] : 1.0f;  // the batch's common query scale
+    // int8: the lane's side of the row bound (coarse_row_bound): tfmax with its own relative slack, rounded up
+    const float tfm = fabsf(tfmax) < 3.0e38f ? fmaf(fabsf(tfmax), 4e-6f, tfmax) : tfmax;
+    const f32x2* rowb = reinterpret_cast<const f32x2*>(q_tf + 1536);
     // hits of this lane: up to 4 queued (local query index, key); a 5th and later ones are flushed directly
     int nh = 0;
     int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
@@ -338,6 +366,12 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int rl = wm * 128 + mi * 16 + fr;
+        int Ti = 0;
+        if (I8) {  // (before anything else of the row block is touched: the common path is this, 8 v_max3 and one branch)
+            const f32x2 ab = rowb[rl];
+            const float tl = fmaf(-tfm, ab[1], ab[0]);
+            Ti = (int)__builtin_amdgcn_fmed3f(tl, -2.0e9f, 2.0e9f);
+        }
         const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;  // exact: the precise test below uses it too
         const float sx = I8 ? q_tf[1280 + rl] : 0.f;  // int8 stage: the integer dot is scaled by s_r s_q
@@ -346,14 +380,12 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         // 0 and c_r = 2 (L2), 1 (IP), 1/|x| (cosine), times s_r s_q in the int8 stage, where every query of the batch shares one
         // scale (sc_launch_query_i8) -- so the right-hand side differs between this lane's 16 queries only through tf_q, and with
         // tfmax = max of those it is bounded below by a per-row constant.  Anything that passes is tested precisely below.
-        float Tlb;
-        // (v_rcp_f32, 1 ulp, instead of an IEEE division: the bound only has to be conservative, and the 4e-6 slack below covers it)
-        if (I8) Tlb = ((METRIC == SC_METRIC_L2 ? xn : 0.f) - tfmax) * __builtin_amdgcn_rcpf(-ar * sq0);
-        else Tlb = (METRIC == SC_METRIC_L2) ? 0.5f * (xn - tfmax) : (METRIC == SC_METRIC_COSINE) ? -tfmax / xs : -tfmax;
-        Tlb = Tlb - fabsf(Tlb) * 4e-6f - (I8 ? 2.0f : 0.f);  // rounding of this bound itself (the precise test has its own slack)
-        int Ti = 0;
-        if (I8) Ti = !(Tlb == Tlb) ? (int)0x80000000 : Tlb <= -2.0e9f ? (int)0x80000000 : Tlb >= 2.0e9f ? 0x7FFFFFFF : (int)Tlb - 1;
-        if (!I8 && !(Tlb == Tlb)) Tlb = -__builtin_inff();  // NaN (0 * inf on an all-zero row): let the precise test decide
+        float Tlb = 0.f;
+        if (!I8) {
+            Tlb = (METRIC == SC_METRIC_L2) ? 0.5f * (xn - tfmax) : (METRIC == SC_METRIC_COSINE) ? -tfmax / xs : -tfmax;
+            Tlb = Tlb - fabsf(Tlb) * 4e-6f;  // rounding of this bound itself (the precise test has its own slack)
+            if (!(Tlb == Tlb)) Tlb = -__builtin_inff();  // NaN (0 * inf on an all-zero row): let the precise test decide
+        }
         // Round 3: first ONE test per row block -- the maximum of the lane's 16 scores (8 v_max3) against the bound, one wave-uniform
         // branch per 16 x 64 scores instead of four; the per-group tests below run only for the row blocks that pass (15-45 % of
         // them).  The bound tests were 1.9 us of a 3.4-4.4 us epilogue at ~28 vector instructions per row block (a wave64
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(512) void scan_coarse256_kernel(CoarseArgs a) {
     coarse256_coords(a, xcd_remap(blockIdx.x, a.ntiles), m0, n0);
     // (requesting the first two K-tiles before this staging -- so that the two memory round trips overlap -- measured no change:
     // entry -> main loop done stayed at 11.2 us per int8 tile)
-    coarse256_stage<I8>(a, m0, n0, smem, tid);
+    coarse256_stage<I8, true, true, METRIC>(a, m0, n0, smem, tid);
     f32x4 acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -994,7 +1026,7 @@ int sc_batched_kprime8(void) { return KPRIME8; }
 static int g_coarse_wgs = 0, g_coarse_persistent = 1;  // sc_diag_set_option
 void sc_scan_set_coarse_workgroups(int v) { g_coarse_wgs = v; }
 void sc_scan_set_coarse_persistent(int v) { g_coarse_persistent = v; }
-#define COARSE_QLDS_BYTES (6 * 256 * 4)
+#define COARSE_QLDS_BYTES (8 * 256 * 4)
 #define COARSEP_LDS_BYTES (4 * T_TILE_BYTES + 2 * COARSE_QLDS_BYTES)
 template <int METRIC, bool I8, bool TRACE = false>
 __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
@@ -1027,6 +1059,7 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
     // multiple of the group of 8 row panels x all query tiles, at 1 024 queries and 256 CUs) apart, so it never does there.
     float* q_cur = reinterpret_cast<float*>(smem + COARSE_QLDS);
     float xn_next = 1.0f, xs_next = 0.0f;
+    const float sq0_batch = I8 ? a.qscale[0] : 1.0f;  // every query of a batch shares one scale (sc_launch_query_i8)
     if (tid >= 256) {
         const int64_t row = m0 + (tid - 256);
         xn_next = row < a.row1 ? a.xnorm[row] : 1.0f;
@@ -1039,7 +1072,12 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
         q_cur = reinterpret_cast<float*>(smem_q + COARSE_QLDS);
         if (tid >= 256) {
             q_cur[768 + tid - 256] = xn_next;
-            if (I8) q_cur[1280 + tid - 256] = xs_next;
+            if (I8) {
+                q_cur[1280 + tid - 256] = xs_next;
+                float A, B;
+                coarse_row_bound<METRIC>(xn_next, xs_next, sq0_batch, A, B);
+                *reinterpret_cast<f32x2*>(q_cur + 1536 + 2 * (tid - 256)) = f32x2{A, B};
+            }
         }
         if (((it & 1) ? n0_odd : n0_even) != n0) {
             coarse256_stage<I8, false, true>(a, m0, n0, smem_q, tid);
