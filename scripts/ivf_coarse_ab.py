@@ -10,20 +10,21 @@ import torch
 from semcode_amd import _native
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+metric = sys.argv[2] if len(sys.argv) > 2 else "L2"
 dim, nlist, nprobe, Q, k = 3072, 4096, 64, 1024, 10
 stream = torch.cuda.Stream()
 rt = _native.Runtime(device=0, stream=stream.cuda_stream)
 dev = torch.device("cuda", 0)
-ix = _native.Index(rt, dim, metric="L2", kind="IVF_FLAT", nlist=nlist)
+ix = _native.Index(rt, dim, metric=metric, kind="IVF_FLAT", nlist=nlist)
 ix.fill_synthetic_clustered(rows, seed=0, nclusters=nlist, spread=0.5)
-qs = _native.Index(rt, dim, metric="L2")
+qs = _native.Index(rt, dim, metric=metric)
 qs.fill_synthetic_clustered(Q, seed=0, nclusters=nlist, spread=0.5, first_row=rows + 12345)
 q = torch.from_numpy(qs.get_rows(0, Q)).to(dev)
 qs.close()
 t0 = time.perf_counter()
 ix.train(niter=10)
 rt.synchronize()
-print(f"train {time.perf_counter() - t0:.1f} s", flush=True)
+print(f"{metric}: train {time.perf_counter() - t0:.1f} s", flush=True)
 od = torch.empty((Q, k), dtype=torch.float32, device=dev)
 orow = torch.empty((Q, k), dtype=torch.int64, device=dev)
 res = {}

@@ -95,6 +95,12 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
 // factors of the per-row error bound the kernel subtracts: score - 2 |dx_r| |q'| - 2 (|x'_r| + |dx_r|) |dq| is a lower bound of
 // |x - q|^2 up to the f32 rounding of the exact path, which the certificate of the re-rank adds), and slot_eps = that bound with the
 // LIST's maxima in place of the row's: the fast test of the kernel must pass whatever any row of the list could pass.
+// IP (template parameter false): <x, q> = <x', q> + <c, q>: only the rows are centred.  The slot's query is q itself (int8, its own
+// scale), the slot constant is <c, q> (plus its rounding allowance: the kernel adds it to the coarse score, which must stay an UPPER
+// bound of the exact inner product), and the pair factors are halved because the row record carries the factor 2 of the L2 form:
+//   score_ub = s_r s_q <x'q, qq> + <c, q> + |dx_r| |q| + (|x'_r| + |dx_r|) |dq|.
+// slot_qnlb = -(<c, q> + allowance): ivf_slot_thr_kernel's "threshold - query norm" then reads T + <c, q>, the bound on -<x', q>.
+template <bool L2>
 __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __restrict__ Qp, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                               const int32_t* __restrict__ slot_q, const int32_t* __restrict__ slot_l, int nslots,
                                                               const unsigned* __restrict__ list_stats, int8_t* __restrict__ Qc8, float* __restrict__ slot_qs,
@@ -113,16 +119,25 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     }
     const float* x = Qp + (int64_t)q * ld;
     const float* c = C + (int64_t)l * ldc;
-    float m = 0.f, nn = 0.f;
+    float m = 0.f, nn = 0.f, cq = 0.f, cn = 0.f;
     for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0) - *reinterpret_cast<const f32x4*>(c + k0);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k0), cv = *reinterpret_cast<const f32x4*>(c + k0);
+        const f32x4 v = L2 ? xv - cv : xv;
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
+        if (!L2) {
+            cq = fmaf(cv[0], xv[0], fmaf(cv[1], xv[1], fmaf(cv[2], xv[2], fmaf(cv[3], xv[3], cq))));
+            cn = fmaf(cv[0], cv[0], fmaf(cv[1], cv[1], fmaf(cv[2], cv[2], fmaf(cv[3], cv[3], cn))));
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         m = fmaxf(m, __shfl_xor(m, off, 64));
         nn += __shfl_xor(nn, off, 64);
+        if (!L2) {
+            cq += __shfl_xor(cq, off, 64);
+            cn += __shfl_xor(cn, off, 64);
+        }
     }
     const float sc = m > 0.f ? m * (1.0f / 127.0f) : 1.0f, inv = 1.0f / sc;
     float res = 0.f;
@@ -131,7 +146,8 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
         if (k0 < ld) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j);
+                if (L2) v = v - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
                 uint32_t word = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -150,13 +166,22 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     if (lane == 0) {
         const float dx = sqrtf(__builtin_bit_cast(float, list_stats[2 * l])), xm = sqrtf(__builtin_bit_cast(float, list_stats[2 * l + 1]));
         const float qn = sqrtf(nn * 1.0001f), dq = sqrtf(res * 1.0001f);
-        // f32 rounding of the coarse score's own terms (stored norms, scaling of the integer dot): taken off the query norm
-        const float round_eps = (4.0e-6f * (xm * xm + nn) + (float)ld * 2.4e-7f * (xm + dx) * qn) * 1.01f + 1e-6f;
         slot_qs[slot] = sc;
-        slot_qnlb[slot] = nn - round_eps;
-        slot_qb[slot] = qn * 1.01f;
-        slot_qd[slot] = dq * 1.01f;
-        slot_eps[slot] = (2.0f * (dx * qn + (xm + dx) * dq)) * 1.03f + 1e-6f;  // >= the kernel's row-wise bound for every row of the list
+        if (L2) {
+            // f32 rounding of the coarse score's own terms (stored norms, scaling of the integer dot): taken off the query norm
+            const float round_eps = (4.0e-6f * (xm * xm + nn) + (float)ld * 2.4e-7f * (xm + dx) * qn) * 1.01f + 1e-6f;
+            slot_qnlb[slot] = nn - round_eps;
+            slot_qb[slot] = qn * 1.01f;
+            slot_qd[slot] = dq * 1.01f;
+            slot_eps[slot] = (2.0f * (dx * qn + (xm + dx) * dq)) * 1.03f + 1e-6f;  // >= the kernel's row-wise bound for every row of the list
+        } else {
+            // rounding of the scaled integer dot and of <c, q> itself (an f32 tree sum here, not the canonical chain)
+            const float round_eps = (4.0e-6f * ((xm + dx) * qn + fabsf(cq)) + (float)ld * 2.4e-7f * (sqrtf(cn) + xm + dx) * qn) * 1.01f + 1e-6f;
+            slot_qnlb[slot] = -(cq + round_eps);
+            slot_qb[slot] = 0.5f * qn * 1.01f;
+            slot_qd[slot] = 0.5f * dq * 1.01f;
+            slot_eps[slot] = (dx * qn + (xm + dx) * dq) * 1.03f + 1e-6f;
+        }
     }
 }
 
@@ -186,10 +211,15 @@ void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, 
     hipLaunchKernelGGL(ivf_center_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow, list_stats);
 }
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
-                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s) {
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,
+                              int metric) {
     if (nslots <= 0) return;
-    hipLaunchKernelGGL(ivf_pair_query_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8,
-                       slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
+    if (metric == SC_METRIC_L2)
+        hipLaunchKernelGGL(ivf_pair_query_kernel<true>, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats,
+                           (int8_t*)Qc8, slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
+    else
+        hipLaunchKernelGGL(ivf_pair_query_kernel<false>, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats,
+                           (int8_t*)Qc8, slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
 }
 void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
                             hipStream_t s) {
@@ -212,13 +242,18 @@ void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const
 #define IVFW_CAP 4096
 int sc_ivf_widen_cap(void) { return IVFW_CAP; }
 
-static __device__ __forceinline__ float ivf_rounding_allowance(const unsigned* __restrict__ xmax_bits, float qnorm2, int ld) {
+static __device__ __forceinline__ float ivf_rounding_allowance(int metric, const unsigned* __restrict__ xmax_bits, float qnorm2, int ld) {
     const float xmax = sqrtf(__builtin_bit_cast(float, xmax_bits[0])), qn = sqrtf(qnorm2);
-    return (2.0f * (float)ld * 1.2e-7f * xmax * qn) * 1.01f + 1e-6f;
+    return ((metric == SC_METRIC_L2 ? 2.0f : 1.0f) * (float)ld * 1.2e-7f * xmax * qn) * 1.01f + 1e-6f;
+}
+// v-space (smaller = better) value of a key: the distance (L2) or minus the inner product (IP)
+static __device__ __forceinline__ float ivf_key_v(int metric, uint64_t key) {
+    const float sc = sc_key_score(metric, key);
+    return metric == SC_METRIC_L2 ? sc : -sc;
 }
 
 // T[q] = (k-th smallest exact distance among the kpa re-scored phase-A candidates) + allowance; +inf if there are fewer than k
-__global__ __launch_bounds__(128) void ivf_bound_kernel(const uint64_t* __restrict__ ekeysA, int kpa, int k, const float* __restrict__ qnorm,
+__global__ __launch_bounds__(128) void ivf_bound_kernel(int metric, const uint64_t* __restrict__ ekeysA, int kpa, int k, const float* __restrict__ qnorm,
                                                          const unsigned* __restrict__ xmax_bits, int ld, float* __restrict__ thr) {
     __shared__ uint64_t keys[512];
     __shared__ float s_t;
@@ -231,14 +266,14 @@ __global__ __launch_bounds__(128) void ivf_bound_kernel(const uint64_t* __restri
         if (key == SC_KEY_MAX) continue;
         int rank = 0;
         for (int j = 0; j < kpa; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
-        if (rank == k - 1) s_t = sc_key_score(SC_METRIC_L2, key) + ivf_rounding_allowance(xmax_bits, qnorm[q], ld);
+        if (rank == k - 1) s_t = ivf_key_v(metric, key) + ivf_rounding_allowance(metric, xmax_bits, qnorm[q], ld);
     }
     __syncthreads();
     if (tid == 0) thr[q] = s_t;
 }
 
 // S of one query -> cand [q][IVFW_CAP], ncand[q]; flags[q] = 1 (exact probe) when a survivor list overflowed or S does not fit
-__global__ __launch_bounds__(256) void ivf_candidates_kernel(const uint64_t* __restrict__ survA, const unsigned* __restrict__ cntA, const uint64_t* __restrict__ bestA, int kpa,
+__global__ __launch_bounds__(256) void ivf_candidates_kernel(int metric, const uint64_t* __restrict__ survA, const unsigned* __restrict__ cntA, const uint64_t* __restrict__ bestA, int kpa,
                                                               const uint64_t* __restrict__ survB, const unsigned* __restrict__ cntB, int cap,
                                                               const float* __restrict__ thr, uint64_t* __restrict__ cand, int* __restrict__ ncand,
                                                               int* __restrict__ flags, int wcap) {
@@ -272,7 +307,7 @@ __global__ __launch_bounds__(256) void ivf_candidates_kernel(const uint64_t* __r
         const bool fromA = i < nA;
         const uint64_t key = fromA ? survA[(size_t)q * cap + i] : survB[(size_t)q * cap + (i - nA)];
         if (fromA && key <= pivot) continue;
-        if (sc_key_score(SC_METRIC_L2, key) <= T) {
+        if (ivf_key_v(metric, key) <= T) {
             const unsigned pos = atomicAdd(&s_n, 1u);
             if (pos < (unsigned)wcap) cand[(size_t)q * IVFW_CAP + pos] = key;
         }
@@ -326,17 +361,17 @@ __global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(int metric, co
     }
 }
 
-void sc_launch_ivf_bound(const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_bound_kernel, dim3((unsigned)Q), dim3(128), 0, s, ekeysA, kpa, k, qnorm, xmax_bits, ld, thr);
+void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_bound_kernel, dim3((unsigned)Q), dim3(128), 0, s, metric, ekeysA, kpa, k, qnorm, xmax_bits, ld, thr);
 }
-void sc_launch_ivf_candidates(const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
+void sc_launch_ivf_candidates(int metric, const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
                               const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_candidates_kernel, dim3((unsigned)Q), dim3(256), 0, s, survA, cntA, bestA, kpa, survB, cntB, cap, thr, cand, ncand, flags,
+    hipLaunchKernelGGL(ivf_candidates_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, survA, cntA, bestA, kpa, survB, cntB, cap, thr, cand, ncand, flags,
                        wcap < IVFW_CAP ? wcap : IVFW_CAP);
 }
-void sc_launch_ivf_refine_finalize(const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist,
-                                   int64_t* out_rows, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, (int)SC_METRIC_L2, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
+void sc_launch_ivf_refine_finalize(int metric, const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base,
+                                   float* out_dist, int64_t* out_rows, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
 }
 // the same for the exhaustive path's collect pass (scan_batched.hip): ekeys [Q][sc_ivf_widen_cap()], any metric, no pre-scored block
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,

@@ -170,13 +170,14 @@ void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int l
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
                                  float* xrow, unsigned* list_stats, hipStream_t s);
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
-                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s);
+                              const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,
+                              int metric = SC_METRIC_L2);
 void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
                             hipStream_t s);
 void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
                           const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, const float* slot_qb, const float* slot_qd,
                           uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s,
-                          const int32_t* slot_dst = nullptr);  // non-null: dense phase (every row survives; count[] preset by the caller)
+                          const int32_t* slot_dst = nullptr, int metric = SC_METRIC_L2);  // non-null: dense phase (every row survives; count[] preset by the caller)
 void sc_launch_scan_rerank_keys_l2(const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
                                    const uint32_t* perm, uint64_t* ekeys, int Q, hipStream_t s);
 void sc_launch_scan_rerank_keys(int metric, const float* X, const float* xnorm, int ld, const float* Qp, const float* qnorm, const uint64_t* cand, const int* ncand, int kp,
@@ -188,11 +189,11 @@ void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, i
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
                                int Q, hipStream_t s);
 int sc_ivf_widen_cap(void);
-void sc_launch_ivf_bound(const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s);
-void sc_launch_ivf_candidates(const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
+void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s);
+void sc_launch_ivf_candidates(int metric, const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
                               const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s);
-void sc_launch_ivf_refine_finalize(const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist,
-                                   int64_t* out_rows, int Q, hipStream_t s);
+void sc_launch_ivf_refine_finalize(int metric, const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base,
+                                   float* out_dist, int64_t* out_rows, int Q, hipStream_t s);
 
 // ivf.hip
 void sc_launch_ivf_plan(const int64_t* probe_rows, int Q, int nprobe, const int64_t* list_off, int nlist, int* seg_base, int64_t* seg_rows,

@@ -813,7 +813,7 @@ static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
 
 bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
     static const bool env_off = [] { const char* e = getenv("SC_IVF_COARSE"); return e && e[0] == '0'; }();
-    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || !ix->perm || ix->metric != SC_METRIC_L2) return false;
+    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || !ix->perm || (ix->metric != SC_METRIC_L2 && ix->metric != SC_METRIC_IP)) return false;
     if (nprobe < 2 || nprobe > 512 || nprobe >= ix->nlist_trained || k < 1 || k > sc_batched_kprime8() / 2) return false;
     if (ix->search_mode == 5) return Q >= 1;
     if (ix->search_mode != 0 || env_off || ix->ivfc_off) return false;
@@ -966,7 +966,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s);
+    const int metric = (int)ix->metric;  // L2, or IP (rows centred only; ivf_coarse.hip)
+    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s, metric);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, kpa, s);
     // phase A is dense: every row of its lists survives, at a known place of survA; the counts are known here
     SC_HIP(hipMemcpyAsync(cnt, cntA.data(), (size_t)Q * 4, hipMemcpyHostToDevice, s));
@@ -978,27 +979,27 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);  // (+inf everywhere; the dense form tests nothing)
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items, (int)items[0].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survA, cnt, IVFC_CAP,
-                             b + o_hits, hit_bytes, s, d_sd);
+                             b + o_hits, hit_bytes, s, d_sd, metric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
     }
     sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-    sc_launch_scan_select(SC_METRIC_L2, survA, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, kpa, s);  // (resets cnt: phase B counts from 0)
-    sc_launch_scan_rerank_keys_l2(ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, nullptr, kpa, ix->perm, ekeysA, Q, s);
-    sc_launch_ivf_bound(ekeysA, kpa, k, ix->qnorm, xmax_bits, ld, thr, Q, s);
+    sc_launch_scan_select(metric, survA, cnt, IVFC_CAP, best, ix->qnorm, thr, tf, ovf, Q, kpa, s);  // (resets cnt: phase B counts from 0)
+    sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, nullptr, kpa, ix->perm, ekeysA, Q, s);
+    sc_launch_ivf_bound(metric, ekeysA, kpa, k, ix->qnorm, xmax_bits, ld, thr, Q, s);
     sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
     // 5. phase B: the other lists against T
     if (!items[1].empty()) {
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + items[0].size() * sizeof(Item), (int)items[1].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb,
-                             d_qd, survB, cnt, IVFC_CAP, b + o_hits, hit_bytes, s);
+                             d_qd, survB, cnt, IVFC_CAP, b + o_hits, hit_bytes, s, nullptr, metric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
     }
     // 6. refine: every row whose lower bound is within T, re-scored exactly; exact top-k
     sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-    sc_launch_ivf_candidates(survA, cntA_d, best, kpa, survB, cnt, IVFC_CAP, thr, cand2, ncand, flags, Q, g_ivf_refine_cap < WCAP ? g_ivf_refine_cap : WCAP, s);
-    sc_launch_scan_rerank_keys_l2(ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, cand2, ncand, WCAP, ix->perm, ekeys2, Q, s);
-    sc_launch_ivf_refine_finalize(ekeysA, kpa, ekeys2, ncand, flags, k, ix->row_base, out_dist, out_rows, Q, s);
+    sc_launch_ivf_candidates(metric, survA, cntA_d, best, kpa, survB, cnt, IVFC_CAP, thr, cand2, ncand, flags, Q, g_ivf_refine_cap < WCAP ? g_ivf_refine_cap : WCAP, s);
+    sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, cand2, ncand, WCAP, ix->perm, ekeys2, Q, s);
+    sc_launch_ivf_refine_finalize(metric, ekeysA, kpa, ekeys2, ncand, flags, k, ix->row_base, out_dist, out_rows, Q, s);
     sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
     SC_HIP(hipGetLastError());
     static const bool trace_c = getenv("SC_IVF_TRACE") != nullptr;  // tuning aid

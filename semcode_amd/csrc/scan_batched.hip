@@ -363,14 +363,38 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
     int nh = 0;
     int hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0;
     uint64_t hk0 = 0, hk1 = 0, hk2 = 0, hk3 = 0;
+    // int8: a first, branch-free pass over the 8 row blocks -- bound, maximum of the lane's 16 scores, one ballot each -- collects
+    // which row blocks hold anything at all; in the late phases of a batch (most of its tiles) none does and the epilogue ends here.
+    // The per-row-block form below is ~2 KB of code per block, nearly all of it cold: its hot path hopped over 17 000 instructions
+    // in eight jumps (2.1-2.3 us per tile with NOTHING passing, profiles/r3k_coarse_trace.log); this pass is ~150 contiguous ones.
+    unsigned blockmask = 0xFFu;
+    int TiA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (I8 && !ROWTEST_OFF) {
+        blockmask = 0u;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const f32x2 ab = rowb[wm * 128 + mi * 16 + fr];
+            const float tl = fmaf(-tfm, ab[1], ab[0]);
+            TiA[mi] = (int)__builtin_amdgcn_fmed3f(tl, -2.0e9f, 2.0e9f);
+            int mx = max(max(__float_as_int(acc[0][mi][0]), __float_as_int(acc[0][mi][1])), max(__float_as_int(acc[0][mi][2]), __float_as_int(acc[0][mi][3])));
+#pragma unroll
+            for (int ni = 1; ni < 4; ++ni)
+                mx = max(max(mx, max(__float_as_int(acc[ni][mi][0]), __float_as_int(acc[ni][mi][1]))), max(__float_as_int(acc[ni][mi][2]), __float_as_int(acc[ni][mi][3])));
+            blockmask |= __any(mx >= TiA[mi]) ? (1u << mi) : 0u;
+        }
+        blockmask = __builtin_amdgcn_readfirstlane(blockmask);
+        if (blockmask == 0u || a.cap == -2) return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
+        if (I8 && !(blockmask & (1u << mi))) continue;
         const int rl = wm * 128 + mi * 16 + fr;
         int Ti = 0;
-        if (I8) {  // (before anything else of the row block is touched: the common path is this, 8 v_max3 and one branch)
-            const f32x2 ab = rowb[rl];
-            const float tl = fmaf(-tfm, ab[1], ab[0]);
-            Ti = (int)__builtin_amdgcn_fmed3f(tl, -2.0e9f, 2.0e9f);
+        if (I8) {
+            if (ROWTEST_OFF) {
+                const f32x2 ab = rowb[rl];
+                Ti = (int)__builtin_amdgcn_fmed3f(fmaf(-tfm, ab[1], ab[0]), -2.0e9f, 2.0e9f);
+            } else Ti = TiA[mi];
         }
         const float xn = x_xn[rl];  // staged at kernel start; rows >= row1 hold +inf (L2) / 0 scale so that they never pass
         const float xs = (METRIC == SC_METRIC_COSINE) ? 1.0f / sqrtf(xn) : 0.f;  // exact: the precise test below uses it too
@@ -390,21 +414,11 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
         // branch per 16 x 64 scores instead of four; the per-group tests below run only for the row blocks that pass (15-45 % of
         // them).  The bound tests were 1.9 us of a 3.4-4.4 us epilogue at ~28 vector instructions per row block (a wave64
         // instruction issues over 4 cycles, two waves share a SIMD); the common path is now 9.
-        {
-            bool any_mi;
-            if (I8) {
-                int mx = max(max(__float_as_int(acc[0][mi][0]), __float_as_int(acc[0][mi][1])), max(__float_as_int(acc[0][mi][2]), __float_as_int(acc[0][mi][3])));
+        if (!I8) {
+            float mx = fmaxf(fmaxf(acc[0][mi][0], acc[0][mi][1]), fmaxf(acc[0][mi][2], acc[0][mi][3]));
 #pragma unroll
-                for (int ni = 1; ni < 4; ++ni)
-                    mx = max(max(mx, max(__float_as_int(acc[ni][mi][0]), __float_as_int(acc[ni][mi][1]))), max(__float_as_int(acc[ni][mi][2]), __float_as_int(acc[ni][mi][3])));
-                any_mi = mx >= Ti;
-            } else {
-                float mx = fmaxf(fmaxf(acc[0][mi][0], acc[0][mi][1]), fmaxf(acc[0][mi][2], acc[0][mi][3]));
-#pragma unroll
-                for (int ni = 1; ni < 4; ++ni) mx = fmaxf(fmaxf(mx, fmaxf(acc[ni][mi][0], acc[ni][mi][1])), fmaxf(acc[ni][mi][2], acc[ni][mi][3]));
-                any_mi = mx >= Tlb;
-            }
-            if (!__any(any_mi) && !ROWTEST_OFF) continue;
+            for (int ni = 1; ni < 4; ++ni) mx = fmaxf(fmaxf(mx, fmaxf(acc[ni][mi][0], acc[ni][mi][1])), fmaxf(acc[ni][mi][2], acc[ni][mi][3]));
+            if (!__any(mx >= Tlb) && !ROWTEST_OFF) continue;
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -413,13 +427,15 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
             if (I8) {
                 // (__float_as_int, not __builtin_bit_cast(int, acc[ni][mi][r]): hipcc lowers the bit_cast of a vector-ELEMENT lvalue as
                 // element 0 -- the first int8 build tested the wrong accumulators for three queries in four)
-                const int a0 = __float_as_int(acc[ni][mi][0]), a1 = __float_as_int(acc[ni][mi][1]), a2 = __float_as_int(acc[ni][mi][2]),
-                          a3 = __float_as_int(acc[ni][mi][3]);
-                g = (a0 >= Ti) | (a1 >= Ti) | (a2 >= Ti) | (a3 >= Ti);
+                // the group's maximum against the bound: 3 instructions instead of 4 compares and 3 ORs (a wave64 instruction issues
+                // over 4 cycles, two waves share a SIMD, and a third of all row blocks get here: SC_COARSE_EXPERIMENT)
+                const int gm = max(max(__float_as_int(acc[ni][mi][0]), __float_as_int(acc[ni][mi][1])),
+                                   max(__float_as_int(acc[ni][mi][2]), __float_as_int(acc[ni][mi][3])));
+                g = gm >= Ti;
             } else {
                 g = (acc[ni][mi][0] >= Tlb) | (acc[ni][mi][1] >= Tlb) | (acc[ni][mi][2] >= Tlb) | (acc[ni][mi][3] >= Tlb);
             }
-            if (!__any(g) || NOPRECISE) continue;  // NOPRECISE: diagnostic (results invalid), what the bound tests alone cost
+            if (!__any(g) || NOPRECISE || a.cap == -3) continue;  // NOPRECISE / cap -3: diagnostic (results invalid), what the bound tests alone cost
             if (TRACE && lane == 0) atomicAdd(&a.trace[(size_t)blockIdx.x * 8 + 4], 1ull);
             f32x4 t;
 #pragma unroll
@@ -438,6 +454,8 @@ static __device__ __forceinline__ void coarse256_epilogue(const CoarseArgs& a, c
                 const int64_t row = m0 + rl;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // (int8: entering the precise test on the integer bound alone -- it is a superset of this float test -- saved these
+                    // 12 instructions per entered group but ran the precise test 1.3x as often: 7.94 -> 7.95 ms of kernels per step)
                     if (row < a.row1 && t[r] <= tf[ni][r]) {
                         if (TRACE) atomicAdd(&a.trace[(size_t)blockIdx.x * 8 + 5], 1ull);
                         const int ql = wn * 64 + ni * 16 + 4 * fq + r;
@@ -1111,7 +1129,7 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (TRACE && tid == 0) a.trace[(size_t)tile * 8 + 2] = (unsigned long long)wall_clock64();
-        coarse256_epilogue<METRIC, I8>(a, acc, m0, n0, smem_q, w, lane);
+        if (a.cap != -1) coarse256_epilogue<METRIC, I8>(a, acc, m0, n0, smem_q, w, lane);  // cap -1 / -2: SC_COARSE_EXPERIMENT (results invalid)
         if (TRACE && tid == 0) a.trace[(size_t)tile * 8 + 3] = (unsigned long long)wall_clock64();
         if (!more) break;
         tile = next;
@@ -1332,8 +1350,9 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                         const int qid = __float_as_int(sl[256 + ql]);
                         if (rowok && qid >= 0) {
                             const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
-                            float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
-                            sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc));
+                            float sc;  // L2: lower bound of the distance; IP: upper bound of the inner product (slot constant = -(<c, q> + allowance))
+                            if (METRIC == SC_METRIC_L2) sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc_score<METRIC>(dotv, xn, sl[128 + ql])));
+                            else sc = fmaf(ec, sl[384 + ql], fmaf(ea, sl[320 + ql], dotv - sl[128 + ql]));
                             const uint32_t pos = (uint32_t)row + (uint32_t)__float_as_int(sl[448 + ql]);
                             if (pos < (uint32_t)a.cap) a.surv[(size_t)qid * a.cap + pos] = sc_make_key<METRIC>(sc, (uint32_t)row);
                         }
@@ -1361,7 +1380,10 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                     if (rowok && t[r] <= tf[ni][r]) {
                         const float dotv = (float)__float_as_int(acc[ni][mi][r]) * (sx * sq[ni][r]);
                         float sc = sc_score<METRIC>(dotv, xn, sl[128 + ql]);
-                        if (GROUPED) sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc));  // the row's own error bound: a lower bound of the exact distance
+                        if (GROUPED) {  // the row's own error bound: a lower bound of the exact distance (L2) / an upper bound of the inner product (IP)
+                            if (METRIC == SC_METRIC_L2) sc = fmaf(-ec, sl[384 + ql], fmaf(-ea, sl[320 + ql], sc));
+                            else sc = fmaf(ec, sl[384 + ql], fmaf(ea, sl[320 + ql], dotv - sl[128 + ql]));
+                        }
                         const float v = (METRIC == SC_METRIC_L2) ? sc : -sc;
                         if (v <= sl[64 + ql]) {  // -inf for padded slots
                             h = true;
@@ -1422,17 +1444,27 @@ static void launch_coarse64s(const CoarseArgs& a, hipStream_t s, void* hit_scrat
     hipLaunchKernelGGL((scan_coarse64s_kernel<METRIC, false>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, GroupedArgs{});
     hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, a.count, a.surv, a.cap);
 }
-// IVF_FLAT coarse stage (L2): `nitems` work items {row0, rows, slot_base} over the centred int8 shadow Xc8 / per-pair queries Qc8; per-slot
+template <int METRIC>
+static void launch_ivf_coarse_m(const CoarseArgs& a, const GroupedArgs& ga, int wgs, u32x4_t* hitlist, unsigned* hitcount, int hitcap, size_t lists, bool dense,
+                                unsigned* count, uint64_t* surv, int cap, hipStream_t s) {
+    static ScDeviceOnce once;
+    sc_device_once(once, [&] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<METRIC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<METRIC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
+    });
+    if (dense) {  // keys go straight to their places
+        hipLaunchKernelGGL((scan_coarse64s_kernel<METRIC, true, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
+        return;
+    }
+    hipLaunchKernelGGL((scan_coarse64s_kernel<METRIC, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
+    hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, count, surv, cap);
+}
+// IVF_FLAT coarse stage (L2 / IP): `nitems` work items {row0, rows, slot_base} over the centred int8 shadow Xc8 / per-pair queries Qc8; per-slot
 // thresholds etc.; hits go to the survivor lists of the slots' queries.  hit_scratch as for the flat form.
 void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,
                           const float* slot_thr, const float* slot_qn, const float* slot_qs, const int32_t* slot_q, const float* slot_qb, const float* slot_qd,
-                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s, const int32_t* slot_dst) {
+                          uint64_t* surv, unsigned* count, int cap, void* hit_scratch, size_t hit_bytes, hipStream_t s, const int32_t* slot_dst, int metric) {
     if (nitems <= 0) return;
-    static ScDeviceOnce once;
-    sc_device_once(once, [&] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_coarse64s_kernel<SC_METRIC_L2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS_BYTES);
-    });
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xc8; a.xnorm = nullptr; a.xscale = nullptr; a.row0 = 0; a.row1 = 0; a.ld = ld8 / 2; a.Qb = (const bf16_t*)Qc8; a.qnorm = nullptr; a.Q = 0; a.qtiles = 1;
     a.thr = nullptr; a.thr_fast = nullptr; a.surv = surv; a.count = count; a.cap = cap; a.ntiles = nitems; a.qscale = nullptr; a.trace = nullptr;
@@ -1445,12 +1477,8 @@ void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const voi
     unsigned* hitcount = (unsigned*)hit_scratch;
     u32x4_t* hitlist = (u32x4_t*)((char*)hit_scratch + off);
     const int hitcap = (int)std::min<size_t>((hit_bytes - off) / (lists * 16), (size_t)1 << 20);
-    if (slot_dst) {  // dense: keys go straight to their places
-        hipLaunchKernelGGL((scan_coarse64s_kernel<SC_METRIC_L2, true, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
-        return;
-    }
-    hipLaunchKernelGGL((scan_coarse64s_kernel<SC_METRIC_L2, true>), dim3((unsigned)wgs), dim3(512), C64_LDS_BYTES, s, a, hitlist, hitcount, hitcap, ga);
-    hipLaunchKernelGGL(scan_hits_scatter_kernel, dim3((unsigned)lists), dim3(64), 0, s, (const u32x4_t*)hitlist, (const unsigned*)hitcount, hitcap, count, surv, cap);
+    if (metric == SC_METRIC_L2) launch_ivf_coarse_m<SC_METRIC_L2>(a, ga, wgs, hitlist, hitcount, hitcap, lists, slot_dst != nullptr, count, surv, cap, s);
+    else launch_ivf_coarse_m<SC_METRIC_IP>(a, ga, wgs, hitlist, hitcount, hitcap, lists, slot_dst != nullptr, count, surv, cap, s);
 }
 bool sc_scan_coarse64_supported(int Q, int ld8, size_t hit_bytes) { return Q >= 1 && Q <= 64 && ld8 >= 128 && (ld8 % 128) == 0 && hit_bytes >= (size_t)2048 * (4 + 64 * 16) + 256; }
 
@@ -1548,6 +1576,9 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
     CoarseArgs a;
     a.Xb = (const bf16_t*)Xb; a.xnorm = xnorm; a.row0 = row0; a.row1 = row1; a.ld = i8 ? ld / 2 : ld; a.Qb = (const bf16_t*)Qb; a.qnorm = qnorm;
     a.Q = Q; a.thr = thr; a.thr_fast = thr_fast; a.surv = surv; a.count = count; a.cap = cap; a.xscale = xscale; a.qscale = qscale;
+    // SC_COARSE_EXPERIMENT=1: the persistent kernel skips its sparse epilogue, 2: runs only the epilogue's first pass (timing experiments; results invalid)
+    static const int experiment = [] { const char* e = getenv("SC_COARSE_EXPERIMENT"); return e ? atoi(e) : 0; }();
+    if (experiment && !dense && row0 > 0) a.cap = -experiment;
     static const char* env64 = getenv("SC_COARSE64");  // A/B: 0 = small batches through the 256-query tiles
     if (i8 && !dense && hit_scratch && (row0 % T_BM) == 0 && sc_scan_coarse64_supported(Q, ld, hit_bytes) && !(env64 && env64[0] == '0') && !getenv("SC_COARSE_TRACE") &&
         !getenv("SC_COARSE_DBG")) {

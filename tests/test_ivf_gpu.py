@@ -376,15 +376,17 @@ def test_search_survives_a_refresh_that_cannot_get_its_memory(rt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", ["L2", "IP"])
 @pytest.mark.parametrize("dim,n,ncl,nlist", [(96, 30_000, 25, 64), (768, 40_000, 40, 64), (2048, 12_000, 20, 32)])
-def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist):
-    """List-major probing behind the int8 coarse stage (lists quantised relative to their centroids, one centred query per (query,
-    list) pair, coarse scores as lower bounds, exact f32 re-rank, certificate; uncertified queries probed again exactly) returns
-    bit for bit what the exact list-major probe returns: tight and loose clusters, empty lists, lists longer than one row tile and
-    wanted by more queries than one group of 64 slots, k up to 64, few workgroups walking many work items."""
+def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist, metric):
+    """List-major probing behind the int8 coarse stage (lists quantised relative to their centroids; L2: one centred query per (query,
+    list) pair, IP: the query itself plus the pair's <c, q>; coarse scores as bounds of the exact score; bound and refine;
+    what it cannot hold probed again exactly) returns bit for bit what the exact list-major probe returns: tight and loose
+    clusters, empty lists, lists longer than one row tile and wanted by more queries than one group of 64 slots, k up to 64, few
+    workgroups walking many work items."""
     X, centers = clustered(n, dim, ncl, seed=41)
     rng = np.random.default_rng(42)
-    ix = _native.Index(rt, dim, metric="L2", kind="IVF_FLAT", nlist=nlist)
+    ix = _native.Index(rt, dim, metric=metric, kind="IVF_FLAT", nlist=nlist)
     ix.add(X)
     ix.train(niter=5)
     try:
@@ -399,7 +401,7 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist)
                 d5, r5 = ix.search(Q, k=k, nprobe=nprobe)
                 st = ix.last_search_stats()
                 assert st["path"] == "ivf_coarse", st
-                assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (dim, nq, k, nprobe, cap, st)
+                assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (metric, dim, nq, k, nprobe, cap, st)
                 if cap < 0:
                     assert st["uncertified"] <= max(2, nq // 8), st  # bound and refine answers the bulk of a clustered batch itself
     finally:
@@ -408,14 +410,15 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist)
         ix.close()
 
 
-def test_coarse_stage_survives_upserts_and_near_duplicates(rt):
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_coarse_stage_survives_upserts_and_near_duplicates(rt, metric):
     """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow.  700 near-duplicates of
     one row (gaps far below any int8 bound) all have lower bounds within reach of the k-th distance: the refine step re-scores them
     all; with the step limited to 8 rows, and for 4500 duplicates (more than it takes on), the exact probe answers.  Same bits
     every time."""
     X, centers = clustered(20_000, 128, 30, seed=51)
     rng = np.random.default_rng(52)
-    ix = _native.Index(rt, 128, metric="L2", kind="IVF_FLAT", nlist=32)
+    ix = _native.Index(rt, 128, metric=metric, kind="IVF_FLAT", nlist=32)
     ix.add(X)
     ix.train(niter=4)
     dup = (X[123][None, :] + 1e-4 * rng.standard_normal((700, 128))).astype(np.float32)
