@@ -808,7 +808,8 @@ extern "C" sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* cent
 // No probed row outside the re-scored set can be closer than the k-th result, so the results are those of the exact list-major path,
 // bit for bit.  Queries whose survivor lists overflow or whose refine set exceeds 4096 rows are probed again exactly
 // (scan_listgemm / scan_exact kernels).
-static const int IVFC_CAP = 8192;  // survivors per query and phase (the whole of the nearest list(s) in phase A)
+static const int IVFC_CAP = 8192;  // survivors per query and phase
+static const int64_t IVFC_PREFIX = 4096;  // rows of one list that phase A takes (all of them are kept: cap > 2 KP + prefix)
 static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
 
 bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
@@ -867,47 +868,58 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     std::vector<int64_t> probes(npairs);
     SC_HIP(hipMemcpyAsync(probes.data(), (char*)ix->ivf_scratch + ((npairs * 4 + 255) & ~(size_t)255), npairs * 8, hipMemcpyDeviceToHost, s));
     SC_HIP(hipStreamSynchronize(s));
-    // 2. plan.  Phase A = rank 0 of every query, phase B = the other ranks; per phase the pairs are bucketed by list (queries in
-    // ascending order: deterministic), cut into groups of 64 slots, and every group meets every 256-row tile of its list.
+    // 2. plan.  Phase A = every query's nearest list(s) -- of a long list only its first IVFC_PREFIX rows: any subset gives a valid
+    // bound, and phase A keeps every row it sees --, phase B = the other lists and what is left of the phase-A lists; per kind the pairs are
+    // bucketed by list (queries in ascending order: deterministic), cut into groups of 64 slots, and every group meets every 256-row
+    // tile of its row range.
     struct Item { long long row0; int rows; int slot_base; };
     std::vector<int32_t> slot_q, slot_l, slot_dst;  // slot_dst (phase A): where the list's rows go in the query's survivor list
-    std::vector<unsigned> cntA((size_t)Q, 0u);       // rows of every query's phase-A lists
+    std::vector<unsigned> cntA((size_t)Q, 0u);       // rows of every query's phase-A ranges
     std::vector<Item> items[2];
     int64_t streamed_rows = 0, unique_rows = 0;
     std::vector<char> touched((size_t)nlist, 0);
+    auto list_len = [&](int64_t l) { return ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l]; };
     // phase A of a query = its nearest lists until they hold 2 KP rows (one list unless the lists are small): enough candidates
-    // for a finite threshold, which phase B needs -- at +inf every row of the other lists would survive
+    // for a tight bound, which phase B needs -- at +inf every row of the other lists would survive
     std::vector<int> ja((size_t)Q, 1);
     for (int q = 0; q < Q; ++q) {
         int64_t cum = 0;
         int j = 0;
         while (j < nprobe && cum < 2 * (int64_t)KP) {
             const int64_t l = probes[(size_t)q * nprobe + j];
-            if (l >= 0 && l < nlist) cum += ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l];
+            if (l >= 0 && l < nlist) cum += std::min<int64_t>(list_len(l), IVFC_PREFIX);
             ++j;
         }
         ja[(size_t)q] = j;
     }
-    for (int ph = 0; ph < 2; ++ph) {
+    for (int kind = 0; kind < 3; ++kind) {  // 0: phase A (prefix of the list); 1: phase B, whole list; 2: phase B, the rest of a phase-A list
+        auto wanted = [&](int q, int j, int64_t l) {
+            if (l < 0 || l >= nlist) return false;
+            const bool inA = j < ja[(size_t)q];
+            return kind == 0 ? inA : kind == 1 ? !inA : (inA && list_len(l) > IVFC_PREFIX);
+        };
         std::vector<int> start((size_t)nlist + 1, 0);
         for (int q = 0; q < Q; ++q)
-            for (int j = ph == 0 ? 0 : ja[(size_t)q], j1 = ph == 0 ? ja[(size_t)q] : nprobe; j < j1; ++j) {
+            for (int j = 0; j < nprobe; ++j) {
                 const int64_t l = probes[(size_t)q * nprobe + j];
-                if (l >= 0 && l < nlist) ++start[(size_t)l + 1];
+                if (wanted(q, j, l)) ++start[(size_t)l + 1];
             }
         for (int l = 0; l < nlist; ++l) start[(size_t)l + 1] += start[(size_t)l];
+        if (start[(size_t)nlist] == 0) continue;
         std::vector<int> fill(start.begin(), start.end() - 1);
         std::vector<int32_t> qs((size_t)start[(size_t)nlist]);
         for (int q = 0; q < Q; ++q)
-            for (int j = ph == 0 ? 0 : ja[(size_t)q], j1 = ph == 0 ? ja[(size_t)q] : nprobe; j < j1; ++j) {
+            for (int j = 0; j < nprobe; ++j) {
                 const int64_t l = probes[(size_t)q * nprobe + j];
-                if (l >= 0 && l < nlist) qs[(size_t)fill[(size_t)l]++] = q;
+                if (wanted(q, j, l)) qs[(size_t)fill[(size_t)l]++] = q;
             }
+        const int ph = kind == 0 ? 0 : 1;
         for (int l = 0; l < nlist; ++l) {
             const int m = start[(size_t)l + 1] - start[(size_t)l];
-            const int64_t first = ix->list_off_h[(size_t)l], end = ix->list_off_h[(size_t)l + 1];
+            const int64_t lfirst = ix->list_off_h[(size_t)l], lend = ix->list_off_h[(size_t)l + 1];
+            const int64_t first = kind == 2 ? lfirst + IVFC_PREFIX : lfirst, end = kind == 0 ? std::min(lend, lfirst + IVFC_PREFIX) : lend;
             if (m == 0 || end <= first) continue;
-            if (!touched[(size_t)l]) { touched[(size_t)l] = 1; unique_rows += end - first; }
+            if (!touched[(size_t)l]) { touched[(size_t)l] = 1; unique_rows += lend - lfirst; }
             for (int c = 0; c < m; c += 64) {
                 const int nq = std::min(64, m - c);
                 const int slot_base = (int)slot_q.size();

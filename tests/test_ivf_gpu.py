@@ -411,6 +411,30 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist,
 
 
 @pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_coarse_stage_with_lists_longer_than_its_survivor_lists(rt, metric):
+    """The reference's own index parameters (nlist 128) put tens of thousands of rows into a list: phase A then takes a 4 096-row
+    prefix of the nearest list (any subset bounds the k-th score) and the rest of that list joins phase B."""
+    X, centers = clustered(90_000, 64, 6, seed=61, spread=0.5)
+    rng = np.random.default_rng(62)
+    ix = _native.Index(rt, 64, metric=metric, kind="IVF_FLAT", nlist=6)
+    ix.add(X)
+    ix.train(niter=4)
+    sizes = ix.ivf_info()["list_sizes"]
+    assert sizes.max() > 8192, sizes
+    Q = (centers[rng.integers(0, 6, size=150)] + 0.5 * rng.standard_normal((150, 64))).astype(np.float32)
+    for nprobe, k in ((2, 10), (5, 33)):
+        ix.set_search_mode("ivf_listmajor")
+        d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
+        ix.set_search_mode("ivf_coarse")
+        d5, r5 = ix.search(Q, k=k, nprobe=nprobe)
+        st = ix.last_search_stats()
+        assert st["path"] == "ivf_coarse", st
+        assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (metric, nprobe, k, st)
+        assert st["uncertified"] <= 15, st
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP"])
 def test_coarse_stage_survives_upserts_and_near_duplicates(rt, metric):
     """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow.  700 near-duplicates of
     one row (gaps far below any int8 bound) all have lower bounds within reach of the k-th distance: the refine step re-scores them
