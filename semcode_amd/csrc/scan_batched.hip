@@ -1072,7 +1072,9 @@ __global__ __launch_bounds__(512) void scan_coarse256p_kernel(CoarseArgs a) {
     for (int h = 0; h < 8; ++h) hook.coop(h, h, va, vw);  // the first tile's first two K-tiles, in ring order from parity 0
     int par = 0, it = 0;
     // Staging without a global round trip in front of every tile: the row side (|x|^2 and the int8 row scale of the tile's 256 rows,
-    // threads 256..511) is loaded one tile ahead into two registers and only WRITTEN to LDS here; the query side (thresholds, norms,
+    // threads 256..511) is loaded one tile ahead into two registers and only WRITTEN to LDS here (the compiler guards that write with
+    // s_waitcnt vmcnt(0) in waves 4-7, which also waits for the prefetched half-tiles; an LDS-DMA form of this staging without that
+    // wait was built and measured: no gain -- 6.98 -> 6.92 ms of kernels with the epilogue switched off, slower with it); the query side (thresholds, norms,
     // scales of the 256 queries) is staged again only when the query tile changes -- a workgroup's tiles are one round (a
     // multiple of the group of 8 row panels x all query tiles, at 1 024 queries and 256 CUs) apart, so it never does there.
     float* q_cur = reinterpret_cast<float*>(smem + COARSE_QLDS);
@@ -1595,7 +1597,8 @@ void sc_launch_scan_coarse(int metric, const void* Xb, const float* xnorm, int64
         a.ntiles = (int)(((row1 - row0 + T_BM - 1) / T_BM) * a.qtiles);
         a.trace = nullptr;
         static const bool trace = getenv("SC_COARSE_TRACE") != nullptr;  // diagnostic: per-workgroup time stamps of the large L2 launches -> stderr
-        if (trace && metric == SC_METRIC_L2 && a.ntiles >= 20000) {
+        static const int trace_min = [] { const char* e = getenv("SC_COARSE_TRACE_MIN"); return e ? atoi(e) : 20000; }();
+        if (trace && metric == SC_METRIC_L2 && a.ntiles >= trace_min) {
             coarse256_trace(a, i8, s);
             return;
         }
