@@ -928,7 +928,28 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         if (rst) return rst;
     }
     if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
-    if (sc_ivf_coarse_applicable(ix, Q, k, nprobe)) return sc_ivf_search_coarse_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    if (sc_ivf_coarse_applicable(ix, Q, k, nprobe)) {
+        // per-query scratch of the coarse stage is ~200 KB (two survivor lists of 8 192 keys, the refine sets): very large batches go
+        // through it in chunks of 4 096 queries (0.8 GB), each a full batch of its own
+        const int chunk = 4096;
+        int uncert = 0;
+        int64_t uniq = 0, streamed = 0;
+        int groups = 0;
+        for (int q0 = 0; q0 < Q; q0 += chunk) {
+            const int nq = std::min(chunk, Q - q0);
+            const sc_status st = sc_ivf_search_coarse_locked(ix, q_dev + (size_t)q0 * ix->dim, nq, k, nprobe, out_dist + (size_t)q0 * k, out_rows + (size_t)q0 * k);
+            if (st) return st;
+            uncert += ix->last_uncertified;
+            uniq = std::max(uniq, ix->last_unique_rows);
+            streamed += ix->last_streamed_rows;
+            groups += ix->last_groups;
+        }
+        ix->last_uncertified = ix->last_ivfc_uncertified = uncert;
+        ix->last_unique_rows = uniq;
+        ix->last_streamed_rows = streamed;
+        ix->last_groups = groups;
+        return SC_OK;
+    }
     if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
         return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);

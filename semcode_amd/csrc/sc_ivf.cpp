@@ -81,6 +81,8 @@ void sc_ivf_drop_lists_locked(sc_index* ix) {
     ix->trained = false;
     ix->shadow_rows = 0;
     ix->shadow8_rows = 0;
+    ix->shadowc_rows = 0;  // the centred shadow of the coarse stage mirrors the lists
+    ix->ivfc_off = false;
 }
 
 // Xo[pos] = X[g[pos]] for the n stored rows, into fresh corpus-sized buffers that replace X / xnorm on success.
@@ -163,6 +165,8 @@ static sc_status ivf_install_lists_locked(sc_index* ix, int nlist, std::vector<i
     ix->dirty_rows.clear();
     ix->nlist_trained = nlist;
     ix->shadow_rows = ix->shadow8_rows = 0;
+    ix->shadowc_rows = 0;  // new lists (a re-train over the same rows included): the centred shadow is rebuilt on the next coarse probe
+    ix->ivfc_off = false;
     ix->uncert_frac = -1.0;
     ix->trained = true;
     return SC_OK;

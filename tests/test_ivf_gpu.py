@@ -410,6 +410,26 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist,
         ix.close()
 
 
+def test_coarse_stage_follows_a_retrain_and_takes_huge_batches_in_chunks(rt):
+    """A second train over the same rows installs other lists: the centred shadow of the coarse stage must be rebuilt (it used to be
+    kept while the row count stayed the same).  A batch of 5 000 queries goes through the stage in chunks of 4 096."""
+    X, centers = clustered(40_000, 96, 30, seed=71)
+    rng = np.random.default_rng(72)
+    Q = (centers[rng.integers(0, 30, size=5000)] + 0.4 * rng.standard_normal((5000, 96))).astype(np.float32)
+    ix = _native.Index(rt, 96, metric="L2", kind="IVF_FLAT", nlist=48)
+    ix.add(X)
+    for niter in (2, 6):  # different centroids, same rows
+        ix.train(niter=niter)
+        ix.set_search_mode("ivf_listmajor")
+        d4, r4 = ix.search(Q, k=10, nprobe=6)
+        ix.set_search_mode("ivf_coarse")
+        d5, r5 = ix.search(Q, k=10, nprobe=6)
+        st = ix.last_search_stats()
+        assert st["path"] == "ivf_coarse", st
+        assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5)), (niter, st)
+    ix.close()
+
+
 @pytest.mark.parametrize("metric", ["L2", "IP"])
 def test_coarse_stage_with_lists_longer_than_its_survivor_lists(rt, metric):
     """The reference's own index parameters (nlist 128) put tens of thousands of rows into a list: phase A then takes a 4 096-row
