@@ -2,7 +2,7 @@ import sys
 sys.path.insert(0, ".")
 import torch
 from semcode_amd import _native
-rows, dim, nlist, nprobe, Q, k = 4_000_000, 3072, 1600, 64, 1024, 10
+rows, dim, nlist, nprobe, Q, k = (int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000), 3072, (int(sys.argv[2]) if len(sys.argv) > 2 else 1600), 64, 1024, 10
 stream = torch.cuda.Stream()
 rt = _native.Runtime(device=0, stream=stream.cuda_stream)
 dev = torch.device("cuda", 0)

@@ -251,7 +251,9 @@ def test_config5_full_size_ivf_flat_10m_x_3072(rt):
         assert np.array_equal(r3, r[:48]) and np.array_equal(bits(d3), bits(d[:48]))
         ix.set_search_mode("auto")
         da, ra = ix.search(Q, k=K, nprobe=NPROBE)  # whatever the planner picks returns the same probe result or the exact one
-        path = ix.last_search_stats()["path"]
+        sta = ix.last_search_stats()
+        path = sta["path"]
+        assert path == "ivf_coarse" and sta["uncertified"] <= NQ // 16, sta  # round 3: the int8 coarse stage (bound and refine) answers such a batch
         assert (np.array_equal(ra, r) and np.array_equal(bits(da), bits(d))) if path.startswith("ivf") else np.array_equal(ra, r_bf)
         assert (r >= 0).all() and (r < N).all() and (np.diff(d, axis=1) >= 0).all()
         for qi in range(0, NQ, 41):  # 25 queries: every returned distance bit-exact on the regenerated rows, order = (distance, row)
