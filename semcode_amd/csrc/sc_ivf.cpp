@@ -896,6 +896,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         }
         ja[(size_t)q] = j;
     }
+    std::vector<int> group_bases;
     for (int kind = 0; kind < 3; ++kind) {  // 0: phase A (prefix of the list); 1: phase B, whole list; 2: phase B, the rest of a phase-A list
         auto wanted = [&](int q, int j, int64_t l) {
             if (l < 0 || l >= nlist) return false;
@@ -924,6 +925,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
             const int64_t first = kind == 2 ? lfirst + IVFC_PREFIX : lfirst, end = kind == 0 ? std::min(lend, lfirst + IVFC_PREFIX) : lend;
             if (m == 0 || end <= first) continue;
             if (!touched[(size_t)l]) { touched[(size_t)l] = 1; unique_rows += lend - lfirst; }
+            group_bases.clear();
             for (int c = 0; c < m; c += 64) {
                 const int nq = std::min(64, m - c);
                 const int slot_base = (int)slot_q.size();
@@ -938,9 +940,15 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
                     }
                     slot_dst.push_back(dst);
                 }
-                for (int64_t r0 = first; r0 < end; r0 += 256) items[ph].push_back({(long long)r0, (int)std::min<int64_t>(256, end - r0), slot_base});
+                group_bases.push_back(slot_base);
                 streamed_rows += end - first;
             }
+            // items of one list: blocks of 8 row tiles, every group's copy of a block right behind the previous group's -- the persistent
+            // grid hands item i to workgroup i mod grid, workgroups 8 apart share an XCD, so the groups of a popular list stream a
+            // tile through the same L2 at the same time instead of one XCD after the other
+            for (int64_t b0 = first; b0 < end; b0 += 8 * 256)
+                for (const int base : group_bases)
+                    for (int64_t r0 = b0; r0 < end && r0 < b0 + 8 * 256; r0 += 256) items[ph].push_back({(long long)r0, (int)std::min<int64_t>(256, end - r0), base});
         }
     }
     const int nslots = (int)slot_q.size();
