@@ -897,27 +897,52 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         ja[(size_t)q] = j;
     }
     std::vector<int> group_bases;
-    for (int kind = 0; kind < 3; ++kind) {  // 0: phase A (prefix of the list); 1: phase B, whole list; 2: phase B, the rest of a phase-A list
-        auto wanted = [&](int q, int j, int64_t l) {
-            if (l < 0 || l >= nlist) return false;
-            const bool inA = j < ja[(size_t)q];
-            return kind == 0 ? inA : kind == 1 ? !inA : (inA && list_len(l) > IVFC_PREFIX);
-        };
-        std::vector<int> start((size_t)nlist + 1, 0);
-        for (int q = 0; q < Q; ++q)
-            for (int j = 0; j < nprobe; ++j) {
-                const int64_t l = probes[(size_t)q * nprobe + j];
-                if (wanted(q, j, l)) ++start[(size_t)l + 1];
+    // the three kinds of (query, list) entries -- 0: phase A (prefix of the list); 1: phase B, whole list; 2: phase B, the rest of a
+    // phase-A list -- bucketed by list in two passes over the probe table (count, fill)
+    std::vector<int> start3[3];
+    std::vector<int32_t> qs3[3];
+    for (int kind = 0; kind < 3; ++kind) start3[kind].assign((size_t)nlist + 1, 0);
+    for (int q = 0; q < Q; ++q) {
+        const int64_t* pq = probes.data() + (size_t)q * nprobe;
+        const int jaq = ja[(size_t)q];
+        for (int j = 0; j < nprobe; ++j) {
+            const int64_t l = pq[j];
+            if (l < 0 || l >= nlist) continue;
+            if (j < jaq) {
+                ++start3[0][(size_t)l + 1];
+                if (list_len(l) > IVFC_PREFIX) ++start3[2][(size_t)l + 1];
+            } else {
+                ++start3[1][(size_t)l + 1];
             }
-        for (int l = 0; l < nlist; ++l) start[(size_t)l + 1] += start[(size_t)l];
+        }
+    }
+    std::vector<int> fill3[3];
+    for (int kind = 0; kind < 3; ++kind) {
+        for (int l = 0; l < nlist; ++l) start3[kind][(size_t)l + 1] += start3[kind][(size_t)l];
+        fill3[kind].assign(start3[kind].begin(), start3[kind].end() - 1);
+        qs3[kind].resize((size_t)start3[kind][(size_t)nlist]);
+    }
+    for (int q = 0; q < Q; ++q) {
+        const int64_t* pq = probes.data() + (size_t)q * nprobe;
+        const int jaq = ja[(size_t)q];
+        for (int j = 0; j < nprobe; ++j) {
+            const int64_t l = pq[j];
+            if (l < 0 || l >= nlist) continue;
+            if (j < jaq) {
+                qs3[0][(size_t)fill3[0][(size_t)l]++] = q;
+                if (list_len(l) > IVFC_PREFIX) qs3[2][(size_t)fill3[2][(size_t)l]++] = q;
+            } else {
+                qs3[1][(size_t)fill3[1][(size_t)l]++] = q;
+            }
+        }
+    }
+    slot_q.reserve(npairs * 2 + 64);
+    slot_l.reserve(npairs * 2 + 64);
+    slot_dst.reserve(npairs * 2 + 64);
+    for (int kind = 0; kind < 3; ++kind) {
+        const std::vector<int>& start = start3[kind];
+        const std::vector<int32_t>& qs = qs3[kind];
         if (start[(size_t)nlist] == 0) continue;
-        std::vector<int> fill(start.begin(), start.end() - 1);
-        std::vector<int32_t> qs((size_t)start[(size_t)nlist]);
-        for (int q = 0; q < Q; ++q)
-            for (int j = 0; j < nprobe; ++j) {
-                const int64_t l = probes[(size_t)q * nprobe + j];
-                if (wanted(q, j, l)) qs[(size_t)fill[(size_t)l]++] = q;
-            }
         const int ph = kind == 0 ? 0 : 1;
         for (int l = 0; l < nlist; ++l) {
             const int m = start[(size_t)l + 1] - start[(size_t)l];
