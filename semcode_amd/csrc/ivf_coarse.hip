@@ -253,37 +253,40 @@ static __device__ __forceinline__ float ivf_key_v(int metric, uint64_t key) {
 }
 
 // T[q] = (k-th smallest exact distance among the kpa re-scored phase-A candidates) + allowance; +inf if there are fewer than k
-__global__ __launch_bounds__(128) void ivf_bound_kernel(int metric, const uint64_t* __restrict__ ekeysA, int kpa, int k, const float* __restrict__ qnorm,
-                                                         const unsigned* __restrict__ xmax_bits, int ld, float* __restrict__ thr) {
-    __shared__ uint64_t keys[512];
+// ekeysT (optional): a second sample of kpa re-scored rows (the two-level bound of long lists); the k-th of the union
+__global__ __launch_bounds__(128) void ivf_bound_kernel(int metric, const uint64_t* __restrict__ ekeysA, int kpa_one, int k, const float* __restrict__ qnorm,
+                                                         const unsigned* __restrict__ xmax_bits, int ld, float* __restrict__ thr,
+                                                         const uint64_t* __restrict__ ekeysT, int keep_min) {
+    __shared__ uint64_t keys[1024];
     __shared__ float s_t;
     const int q = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < kpa; i += 128) keys[i] = ekeysA[(size_t)q * kpa + i];
+    const int kpa = ekeysT ? 2 * kpa_one : kpa_one;
+    for (int i = tid; i < kpa; i += 128) keys[i] = i < kpa_one ? ekeysA[(size_t)q * kpa_one + i] : ekeysT[(size_t)q * kpa_one + (i - kpa_one)];
     if (tid == 0) s_t = __builtin_inff();
     __syncthreads();
     for (int i = tid; i < kpa; i += 128) {
         const uint64_t key = keys[i];
         if (key == SC_KEY_MAX) continue;
         int rank = 0;
-        for (int j = 0; j < kpa; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
+        for (int j = 0; j < kpa; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word; the two samples are disjoint rows)
         if (rank == k - 1) s_t = ivf_key_v(metric, key) + ivf_rounding_allowance(metric, xmax_bits, qnorm[q], ld);
     }
     __syncthreads();
-    if (tid == 0) thr[q] = s_t;
+    if (tid == 0) thr[q] = keep_min ? fminf(thr[q], s_t) : s_t;  // (every such bound is valid, so is their minimum)
 }
 
 // S of one query -> cand [q][IVFW_CAP], ncand[q]; flags[q] = 1 (exact probe) when a survivor list overflowed or S does not fit
 __global__ __launch_bounds__(256) void ivf_candidates_kernel(int metric, const uint64_t* __restrict__ survA, const unsigned* __restrict__ cntA, const uint64_t* __restrict__ bestA, int kpa,
                                                               const uint64_t* __restrict__ survB, const unsigned* __restrict__ cntB, int cap,
                                                               const float* __restrict__ thr, uint64_t* __restrict__ cand, int* __restrict__ ncand,
-                                                              int* __restrict__ flags, int wcap) {
+                                                              int* __restrict__ flags, int wcap, int capB) {
     __shared__ unsigned s_n;
     __shared__ uint64_t wmax[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) s_n = 0;
     const unsigned nA = cntA[q], nB = cntB[q];
     const float T = thr[q];
-    if (nA > (unsigned)cap || nB > (unsigned)cap || !(T < __builtin_inff())) {  // uniform over the workgroup
+    if (nA > (unsigned)cap || nB > (unsigned)capB || !(T < __builtin_inff())) {  // uniform over the workgroup
         if (tid == 0) { ncand[q] = 0; flags[q] = 1; }
         return;
     }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void ivf_candidates_kernel(int metric, const u
     for (int w = 1; w < 4; ++w) pivot = wmax[w] > pivot ? wmax[w] : pivot;
     for (unsigned i = tid; i < nA + nB; i += 256) {
         const bool fromA = i < nA;
-        const uint64_t key = fromA ? survA[(size_t)q * cap + i] : survB[(size_t)q * cap + (i - nA)];
+        const uint64_t key = fromA ? survA[(size_t)q * cap + i] : survB[(size_t)q * capB + (i - nA)];
         if (fromA && key <= pivot) continue;
         if (ivf_key_v(metric, key) <= T) {
             const unsigned pos = atomicAdd(&s_n, 1u);
@@ -361,13 +364,14 @@ __global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(int metric, co
     }
 }
 
-void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_bound_kernel, dim3((unsigned)Q), dim3(128), 0, s, metric, ekeysA, kpa, k, qnorm, xmax_bits, ld, thr);
+void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s,
+                         const uint64_t* ekeysT, bool keep_min) {
+    hipLaunchKernelGGL(ivf_bound_kernel, dim3((unsigned)Q), dim3(128), 0, s, metric, ekeysA, kpa, k, qnorm, xmax_bits, ld, thr, ekeysT, keep_min ? 1 : 0);
 }
 void sc_launch_ivf_candidates(int metric, const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
-                              const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s) {
+                              const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s, int capB) {
     hipLaunchKernelGGL(ivf_candidates_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, survA, cntA, bestA, kpa, survB, cntB, cap, thr, cand, ncand, flags,
-                       wcap < IVFW_CAP ? wcap : IVFW_CAP);
+                       wcap < IVFW_CAP ? wcap : IVFW_CAP, capB > 0 ? capB : cap);
 }
 void sc_launch_ivf_refine_finalize(int metric, const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base,
                                    float* out_dist, int64_t* out_rows, int Q, hipStream_t s) {

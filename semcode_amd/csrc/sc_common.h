@@ -189,9 +189,10 @@ void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, i
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
                                int Q, hipStream_t s);
 int sc_ivf_widen_cap(void);
-void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s);
+void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s,
+                         const uint64_t* ekeysT = nullptr, bool keep_min = false);
 void sc_launch_ivf_candidates(int metric, const uint64_t* survA, const unsigned* cntA, const uint64_t* bestA, int kpa, const uint64_t* survB, const unsigned* cntB, int cap,
-                              const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s);
+                              const float* thr, uint64_t* cand, int* ncand, int* flags, int Q, int wcap, hipStream_t s, int capB = 0);
 void sc_launch_ivf_refine_finalize(int metric, const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base,
                                    float* out_dist, int64_t* out_rows, int Q, hipStream_t s);
 

@@ -812,7 +812,8 @@ extern "C" sc_status sc_index_ivf_info(sc_index* ix, int32_t* nlist, float* cent
 // No probed row outside the re-scored set can be closer than the k-th result, so the results are those of the exact list-major path,
 // bit for bit.  Queries whose survivor lists overflow or whose refine set exceeds 4096 rows are probed again exactly
 // (scan_listgemm / scan_exact kernels).
-static const int IVFC_CAP = 8192;  // survivors per query and phase
+static const int IVFC_CAP = 8192;  // survivors per query, phase A (everything it sees: 2 KP + one prefix at most)
+static const int IVFC_CAPB = 16384; // ... and phase B (the rest of a long nearest list against the prefix's bound can be thousands)
 static const int64_t IVFC_PREFIX = 4096;  // rows of one list that phase A takes (all of them are kept: cap > 2 KP + prefix)
 static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
 
@@ -879,7 +880,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     struct Item { long long row0; int rows; int slot_base; };
     std::vector<int32_t> slot_q, slot_l, slot_dst;  // slot_dst (phase A): where the list's rows go in the query's survivor list
     std::vector<unsigned> cntA((size_t)Q, 0u);       // rows of every query's phase-A ranges
-    std::vector<Item> items[2];
+    std::vector<Item> items[3];  // phase A | the rest of long phase-A lists | the other lists
     int64_t streamed_rows = 0, unique_rows = 0;
     std::vector<char> touched((size_t)nlist, 0);
     auto list_len = [&](int64_t l) { return ix->list_off_h[(size_t)l + 1] - ix->list_off_h[(size_t)l]; };
@@ -939,11 +940,12 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     slot_q.reserve(npairs * 2 + 64);
     slot_l.reserve(npairs * 2 + 64);
     slot_dst.reserve(npairs * 2 + 64);
-    for (int kind = 0; kind < 3; ++kind) {
+    int64_t rows_kind[3] = {0, 0, 0};
+    for (int kind : {0, 2, 1}) {  // (in this order in memory: the tails form a launch of their own when the bound has two levels)
         const std::vector<int>& start = start3[kind];
         const std::vector<int32_t>& qs = qs3[kind];
         if (start[(size_t)nlist] == 0) continue;
-        const int ph = kind == 0 ? 0 : 1;
+        const int ph = kind == 0 ? 0 : kind == 2 ? 1 : 2;
         for (int l = 0; l < nlist; ++l) {
             const int m = start[(size_t)l + 1] - start[(size_t)l];
             const int64_t lfirst = ix->list_off_h[(size_t)l], lend = ix->list_off_h[(size_t)l + 1];
@@ -967,6 +969,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
                 }
                 group_bases.push_back(slot_base);
                 streamed_rows += end - first;
+                rows_kind[kind] += (end - first) * nq;
             }
             // items of one list: blocks of 8 row tiles, every group's copy of a block right behind the previous group's -- the persistent
             // grid hands item i to workgroup i mod grid, workgroups 8 apart share an XCD, so the groups of a popular list stream a
@@ -977,7 +980,12 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         }
     }
     const int nslots = (int)slot_q.size();
-    const size_t nitems = items[0].size() + items[1].size();
+    const size_t nitems = items[0].size() + items[1].size() + items[2].size();
+    // Long lists (the reference's nlist = 128: tens of thousands of rows each): the bound from a 4 096-row prefix of the nearest list is
+    // loose, and against it the REST of that list -- where most neighbours are -- overflows the survivor lists (10M x 768, nlist 128:
+    // 65 of 1 024 queries).  Then the bound gets a second level: the tails run first, their 128 best lower bounds are re-scored too,
+    // and the other lists meet the bound of both samples.
+    const bool two_level = !items[1].empty() && rows_kind[2] * 4 >= rows_kind[0];
     // 3. scratch: slot tables, per-pair queries, per-query state, survivor lists of both phases, hit lists, the refine stage's sets
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -989,7 +997,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
                  o_se = carve((size_t)nslots * 4), o_sd = carve((size_t)nslots * 4), o_items = carve(nitems * sizeof(Item)), o_qc = carve((size_t)nslots * ld8),
                  o_thr = carve((size_t)Qpad * 4), o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_cntA = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4),
                  o_flag = carve((size_t)Q * 4), o_nc = carve((size_t)Q * 4), o_best = carve((size_t)Q * kpa * 8), o_ekA = carve((size_t)Q * kpa * 8),
-                 o_survA = carve((size_t)Q * IVFC_CAP * 8), o_survB = carve((size_t)Q * IVFC_CAP * 8), o_cand = carve((size_t)Q * WCAP * 8),
+                 o_bestT = carve((size_t)Q * kpa * 8), o_ekT = carve((size_t)Q * kpa * 8), o_cntT = carve((size_t)Q * 4), o_thrT = carve((size_t)Qpad * 4), o_tfT = carve((size_t)Qpad * 4),
+                 o_survA = carve((size_t)Q * IVFC_CAP * 8), o_survB = carve((size_t)Q * IVFC_CAPB * 8), o_cand = carve((size_t)Q * WCAP * 8),
                  o_ek2 = carve((size_t)Q * WCAP * 8);
     const size_t hit_bytes = (size_t)2048 * (4 + 8192 * 16) + 256;
     const size_t o_hits = carve(hit_bytes);
@@ -1010,6 +1019,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     if (!items[0].empty()) SC_HIP(hipMemcpyAsync(b + o_items, items[0].data(), items[0].size() * sizeof(Item), hipMemcpyHostToDevice, s));
     if (!items[1].empty())
         SC_HIP(hipMemcpyAsync(b + o_items + items[0].size() * sizeof(Item), items[1].data(), items[1].size() * sizeof(Item), hipMemcpyHostToDevice, s));
+    if (!items[2].empty())
+        SC_HIP(hipMemcpyAsync(b + o_items + (items[0].size() + items[1].size()) * sizeof(Item), items[2].data(), items[2].size() * sizeof(Item), hipMemcpyHostToDevice, s));
     st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
     if (st) return st;
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
@@ -1036,17 +1047,47 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, nullptr, kpa, ix->perm, ekeysA, Q, s);
     sc_launch_ivf_bound(metric, ekeysA, kpa, k, ix->qnorm, xmax_bits, ld, thr, Q, s);
     sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
-    // 5. phase B: the other lists against T
-    if (!items[1].empty()) {
+    // 5. phase B: the other lists (and the rest of long phase-A lists) against T
+    size_t b_first = items[0].size(), b_count = items[1].size() + items[2].size();
+    // (two-level bounds) the 128 best lower bounds among phase B's survivors so far, re-scored: T = min(T, k-th of that sample + phase A's)
+    auto tighten = [&]() -> sc_status {
+        uint64_t *bestT = (uint64_t*)(b + o_bestT), *ekeysT = (uint64_t*)(b + o_ekT);
+        unsigned* cntT = (unsigned*)(b + o_cntT);
+        sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+        SC_HIP(hipMemcpyAsync(cntT, cnt, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));  // (the selection resets the counts; the survivors stay where they are)
+        SC_HIP(hipMemsetAsync(bestT, 0xFF, (size_t)Q * kpa * 8, s));
+        sc_launch_scan_select(metric, survB, cnt, IVFC_CAPB, bestT, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), ovf, Q, kpa, s);
+        SC_HIP(hipMemcpyAsync(cnt, cntT, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
+        sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, bestT, nullptr, kpa, ix->perm, ekeysT, Q, s);
+        sc_launch_ivf_bound(metric, ekeysA, kpa, k, ix->qnorm, xmax_bits, ld, thr, Q, s, ekeysT, true);
+        sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+        return SC_OK;
+    };
+    if (two_level) {  // the tails first: most neighbours live there, and what they yield tightens T for the other lists
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
-        sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + items[0].size() * sizeof(Item), (int)items[1].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb,
-                             d_qd, survB, cnt, IVFC_CAP, b + o_hits, hit_bytes, s, nullptr, metric);
+        sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + b_first * sizeof(Item), (int)items[1].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survB,
+                             cnt, IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, metric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+        st = tighten();
+        if (st) return st;
+        b_first += items[1].size();
+        b_count = items[2].size();
+    }
+    if (b_count > 0) {
+        sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
+        sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+        sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + b_first * sizeof(Item), (int)b_count, d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survB, cnt,
+                             IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, metric);
+        sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+    }
+    if (two_level && b_count > 0) {  // ... and once more over everything phase B kept: a query between two clusters finds its neighbours in the other lists
+        st = tighten();
+        if (st) return st;
     }
     // 6. refine: every row whose lower bound is within T, re-scored exactly; exact top-k
     sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-    sc_launch_ivf_candidates(metric, survA, cntA_d, best, kpa, survB, cnt, IVFC_CAP, thr, cand2, ncand, flags, Q, g_ivf_refine_cap < WCAP ? g_ivf_refine_cap : WCAP, s);
+    sc_launch_ivf_candidates(metric, survA, cntA_d, best, kpa, survB, cnt, IVFC_CAP, thr, cand2, ncand, flags, Q, g_ivf_refine_cap < WCAP ? g_ivf_refine_cap : WCAP, s, IVFC_CAPB);
     sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, cand2, ncand, WCAP, ix->perm, ekeys2, Q, s);
     sc_launch_ivf_refine_finalize(metric, ekeysA, kpa, ekeys2, ncand, flags, k, ix->row_base, out_dist, out_rows, Q, s);
     sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
@@ -1071,7 +1112,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         int novf = 0, ninf = 0, nc_max = 0, ja_max = 0;
         double nc_sum = 0, cb_sum = 0, ca_sum = 0, ja_sum = 0;
         for (int i = 0; i < Q; ++i) {
-            novf += hcb[i] > (unsigned)IVFC_CAP || cntA[(size_t)i] > (unsigned)IVFC_CAP;
+            novf += hcb[i] > (unsigned)IVFC_CAPB || cntA[(size_t)i] > (unsigned)IVFC_CAP;
             ninf += !(hthr[i] < 1e30f);
             nc_max = std::max(nc_max, hnc[i]);
             nc_sum += hnc[i];
@@ -1081,8 +1122,9 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
             ja_sum += ja[(size_t)i];
         }
         fprintf(stderr, "[ivf coarse] Q %d: to the exact probe %d (survivor overflow %d, bound +inf %d); re-scored per query %d + avg %.1f max %d; phase A rows avg %.0f, "
-                        "phase B survivors avg %.1f; phase A lists per query avg %.2f max %d; items %zu + %zu, slots %d; streamed %.1f GB int8\n",
-                Q, R, novf, ninf, kpa, nc_sum / Q, nc_max, ca_sum / Q, cb_sum / Q, ja_sum / Q, ja_max, items[0].size(), items[1].size(), nslots,
+                        "phase B survivors avg %.1f; phase A lists per query avg %.2f max %d; items %zu + %zu%s + %zu, slots %d; streamed %.1f GB int8\n",
+                Q, R, novf, ninf, kpa, nc_sum / Q, nc_max, ca_sum / Q, cb_sum / Q, ja_sum / Q, ja_max, items[0].size(), items[1].size(), two_level ? " (own level)" : "",
+                items[2].size(), nslots,
                 (double)streamed_rows * ld8 / 1e9);
     }
     if (ix->search_mode == 0 && Q >= 32 && R * 4 > Q) ix->ivfc_off = true;  // this index does not quantise well enough: later batches probe exactly
