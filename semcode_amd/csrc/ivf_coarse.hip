@@ -120,15 +120,21 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     const float* x = Qp + (int64_t)q * ld;
     const float* c = C + (int64_t)l * ldc;
     float m = 0.f, nn = 0.f, cq = 0.f, cn = 0.f;
+    f32x4 cq4 = {0.f, 0.f, 0.f, 0.f}, cn4 = {0.f, 0.f, 0.f, 0.f};  // (element-wise accumulators: a scalar fmaf chain over the elements came out
+                                                                   // of hipcc as v_pk_fma_f32 with op_sel -- tests/test_isa.py)
     for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k0), cv = *reinterpret_cast<const f32x4*>(c + k0);
         const f32x4 v = L2 ? xv - cv : xv;
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
         if (!L2) {
-            cq = fmaf(cv[0], xv[0], fmaf(cv[1], xv[1], fmaf(cv[2], xv[2], fmaf(cv[3], xv[3], cq))));
-            cn = fmaf(cv[0], cv[0], fmaf(cv[1], cv[1], fmaf(cv[2], cv[2], fmaf(cv[3], cv[3], cn))));
+            cq4 = __builtin_elementwise_fma(cv, xv, cq4);
+            cn4 = __builtin_elementwise_fma(cv, cv, cn4);
         }
+    }
+    if (!L2) {
+        cq = (cq4[0] + cq4[1]) + (cq4[2] + cq4[3]);
+        cn = (cn4[0] + cn4[1]) + (cn4[2] + cn4[3]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -1363,13 +1363,20 @@ __global__ __launch_bounds__(512) void scan_coarse64s_kernel(CoarseArgs a, u32x4
                 for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
                 continue;
             }
+            // (the row factor as a real register pair: -s_r taken straight from the odd half of the row record came out of hipcc as
+            // v_pk_mul_f32 ... op_sel:[1,0], the encoding tests/test_isa.py keeps out of every kernel)
+            f32x2 ar2 = {ar, ar};
+            asm volatile("" : "+v"(ar2));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 t;
                 bool g = false;
+                const f32x2 av01 = f32x2{(float)__float_as_int(acc[ni][mi][0]), (float)__float_as_int(acc[ni][mi][1])} * ar2;
+                const f32x2 av23 = f32x2{(float)__float_as_int(acc[ni][mi][2]), (float)__float_as_int(acc[ni][mi][3])} * ar2;
+                const f32x4 av4 = {av01[0], av01[1], av23[0], av23[1]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float av = (float)__float_as_int(acc[ni][mi][r]) * ar;
+                    const float av = av4[r];
                     t[r] = (METRIC == SC_METRIC_L2) ? fmaf(av, sq[ni][r], xn) : av * sq[ni][r];
                     g |= t[r] <= tf[ni][r];
                 }
