@@ -938,6 +938,15 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         for (int q0 = 0; q0 < Q; q0 += chunk) {
             const int nq = std::min(chunk, Q - q0);
             const sc_status st = sc_ivf_search_coarse_locked(ix, q_dev + (size_t)q0 * ix->dim, nq, k, nprobe, out_dist + (size_t)q0 * k, out_rows + (size_t)q0 * k);
+            if (st == SC_ERR_NOMEM && q0 == 0) {
+                // no room for the centred shadow (a quarter of the corpus again) or the stage's scratch: the exact probes need neither.
+                // The stage stays off until the lists are rebuilt (a failed hipMalloc of tens of GB per search is not free either).
+                (void)hipGetLastError();
+                ix->ivfc_off = true;
+                hipFree(ix->Xc8); ix->Xc8 = nullptr; ix->xc8_cap = 0; ix->shadowc_rows = 0;
+                hipFree(ix->ivfc_scratch); ix->ivfc_scratch = nullptr; ix->ivfc_scratch_cap = 0;
+                goto exact_probe;
+            }
             if (st) return st;
             uncert += ix->last_uncertified;
             uniq = std::max(uniq, ix->last_unique_rows);
@@ -950,6 +959,7 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         ix->last_groups = groups;
         return SC_OK;
     }
+exact_probe:
     if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
         return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);

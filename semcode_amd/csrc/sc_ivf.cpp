@@ -450,7 +450,7 @@ bool sc_ivf_listmajor_applicable(const sc_index* ix, int Q, int k, int nprobe, b
     if (nprobe < 1 || nprobe > 512 || nprobe >= ix->nlist_trained || (ix->search_mode >= 1 && ix->search_mode <= 3)) return false;
     ScanPlan plan;
     if (!ivf_listmajor_plan(ix, k, nprobe, &plan)) return false;
-    if (ix->search_mode == 4) return true;
+    if (ix->search_mode == 4 || ix->search_mode == 5) return true;  // (5: the coarse stage was asked for and could not run)
     // auto: probe while that is estimated to be cheaper than the exhaustive paths (which return exact results).
     // Queries follow the data, so a list is expected to receive (query, list) pairs in proportion to its length:
     // work = sum over lists of len * groups(len).  The batched exhaustive path re-runs uncertified queries through the exact
@@ -827,8 +827,11 @@ bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
     return Q >= 64 && (int64_t)Q * nprobe >= ix->nlist_trained && ix->n >= 100000;
 }
 
+static int g_ivfc_nomem = 0;  // sc_diag_set_option("ivf_coarse_nomem", 1): the centred shadow cannot be allocated (tests of the fallback to the exact probe)
+void sc_ivf_set_coarse_nomem(int v) { g_ivfc_nomem = v; }
 static sc_status ivfc_ensure_shadow(sc_index* ix) {
     if (ix->shadowc_rows == ix->ivf_rows && ix->Xc8) return SC_OK;
+    if (g_ivfc_nomem) return sc_fail(SC_ERR_NOMEM, "ivf coarse stage: out of device memory (forced by sc_diag_set_option)");
     hipStream_t s = ix->rt->stream;
     const int ld8 = ivfc_ld8(ix), nlist = ix->nlist_trained;
     const int64_t rows = ix->ivf_rows, rows_pad = (rows + 255) / 256 * 256 + 256;  // (a list's last tile reads up to 255 rows beyond its end)

@@ -432,6 +432,35 @@ def test_coarse_stage_follows_a_retrain_and_takes_huge_batches_in_chunks(rt):
     ix.close()
 
 
+def test_coarse_stage_without_room_for_its_shadow_leaves_the_exact_probe_in_charge(rt):
+    """The centred int8 shadow is a quarter of the corpus again; when it cannot be allocated the batch is probed exactly (same
+    results), the stage stays off for this index, and a re-train brings it back."""
+    X, centers = clustered(40_000, 96, 30, seed=81)
+    rng = np.random.default_rng(82)
+    Q = (centers[rng.integers(0, 30, size=200)] + 0.4 * rng.standard_normal((200, 96))).astype(np.float32)
+    ix = _native.Index(rt, 96, metric="L2", kind="IVF_FLAT", nlist=48)
+    ix.add(X)
+    ix.train(niter=3)
+    ix.set_search_mode("ivf_listmajor")
+    d4, r4 = ix.search(Q, k=10, nprobe=6)
+    try:
+        _native.diag_set_option("ivf_coarse_nomem", 1)
+        ix.set_search_mode("ivf_coarse")
+        d5, r5 = ix.search(Q, k=10, nprobe=6)
+        assert ix.last_search_stats()["path"] == "ivf_listmajor"
+        assert np.array_equal(r4, r5) and np.array_equal(bits(d4), bits(d5))
+    finally:
+        _native.diag_set_option("ivf_coarse_nomem", 0)
+    ix.train(niter=3)
+    ix.set_search_mode("ivf_coarse")
+    d6, r6 = ix.search(Q, k=10, nprobe=6)
+    assert ix.last_search_stats()["path"] == "ivf_coarse"
+    ix.set_search_mode("ivf_listmajor")
+    d7, r7 = ix.search(Q, k=10, nprobe=6)
+    assert np.array_equal(r6, r7) and np.array_equal(bits(d6), bits(d7))
+    ix.close()
+
+
 @pytest.mark.parametrize("metric", ["L2", "IP"])
 def test_coarse_stage_with_lists_longer_than_its_survivor_lists(rt, metric):
     """The reference's own index parameters (nlist 128) put tens of thousands of rows into a list: phase A then takes a 4 096-row
