@@ -34,9 +34,14 @@ static __device__ __forceinline__ int list_of_pos(const int64_t* __restrict__ li
 }
 
 // one wave per stored row; list_stats[list] = {bits of max |x' - s q|^2, bits of max |x'|^2}
+// UNIT (COSINE): cos(x, q) = <x / |x|, q / |q|>, the inner product of the normalised vectors, and that form may be shifted by ANY vector
+// per list: x' = x / |x| - c / |c| (the normalised centroid keeps |x'| small for lists built by cosine).  The coarse stage then runs
+// its IP form on unit vectors; the exact re-score uses the canonical cosine of the original rows as everywhere else.
+template <bool UNIT>
 __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __restrict__ X, int64_t rows, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                                  const int64_t* __restrict__ list_off, int nlist, int8_t* __restrict__ Xc8,
-                                                                 f32x4* __restrict__ xrow, unsigned* __restrict__ list_stats) {
+                                                                 f32x4* __restrict__ xrow, unsigned* __restrict__ list_stats,
+                                                                 const float* __restrict__ xnorm, const float* __restrict__ cnorm) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -44,9 +49,16 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
         const int l = list_of_pos(list_off, nlist, r);
         const float* x = X + r * (int64_t)ld;
         const float* c = C + (int64_t)l * ldc;
+        float rx = 1.0f, rc = 1.0f;
+        if (UNIT) {
+            const float xn = xnorm[r], cn = cnorm[l];
+            rx = xn > 0.f ? 1.0f / sqrtf(xn) : 0.f;
+            rc = cn > 0.f ? 1.0f / sqrtf(cn) : 0.f;
+        }
         float m = 0.f, nn = 0.f;
         for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0) - *reinterpret_cast<const f32x4*>(c + k0);
+            const f32x4 v = UNIT ? *reinterpret_cast<const f32x4*>(x + k0) * rx - *reinterpret_cast<const f32x4*>(c + k0) * rc
+                                 : *reinterpret_cast<const f32x4*>(x + k0) - *reinterpret_cast<const f32x4*>(c + k0);
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
         }
@@ -63,7 +75,8 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
             if (k0 < ld) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
+                    const f32x4 v = UNIT ? *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) * rx - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j) * rc
+                                         : *reinterpret_cast<const f32x4*>(x + k0 + 4 * j) - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
                     uint32_t word = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -100,12 +113,13 @@ __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __r
 // bound of the exact inner product), and the pair factors are halved because the row record carries the factor 2 of the L2 form:
 //   score_ub = s_r s_q <x'q, qq> + <c, q> + |dx_r| |q| + (|x'_r| + |dx_r|) |dq|.
 // slot_qnlb = -(<c, q> + allowance): ivf_slot_thr_kernel's "threshold - query norm" then reads T + <c, q>, the bound on -<x', q>.
-template <bool L2>
+// UNIT (COSINE; with L2 = false): the IP form on q / |q| and c / |c| (ivf_center_shadow_kernel<true>).
+template <bool L2, bool UNIT = false>
 __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __restrict__ Qp, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                               const int32_t* __restrict__ slot_q, const int32_t* __restrict__ slot_l, int nslots,
                                                               const unsigned* __restrict__ list_stats, int8_t* __restrict__ Qc8, float* __restrict__ slot_qs,
                                                               float* __restrict__ slot_qnlb, float* __restrict__ slot_qb, float* __restrict__ slot_qd,
-                                                              float* __restrict__ slot_eps) {
+                                                              float* __restrict__ slot_eps, const float* __restrict__ qnorm, const float* __restrict__ cnorm) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int slot = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -119,11 +133,18 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
     }
     const float* x = Qp + (int64_t)q * ld;
     const float* c = C + (int64_t)l * ldc;
+    float rq = 1.0f, rc = 1.0f;
+    if (UNIT) {
+        const float qn2 = qnorm[q], cn2 = cnorm[l];
+        rq = qn2 > 0.f ? 1.0f / sqrtf(qn2) : 0.f;
+        rc = cn2 > 0.f ? 1.0f / sqrtf(cn2) : 0.f;
+    }
     float m = 0.f, nn = 0.f, cq = 0.f, cn = 0.f;
     f32x4 cq4 = {0.f, 0.f, 0.f, 0.f}, cn4 = {0.f, 0.f, 0.f, 0.f};  // (element-wise accumulators: a scalar fmaf chain over the elements came out
                                                                    // of hipcc as v_pk_fma_f32 with op_sel -- tests/test_isa.py)
     for (int k0 = 4 * lane; k0 < ld; k0 += 256) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k0), cv = *reinterpret_cast<const f32x4*>(c + k0);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + k0), cv = *reinterpret_cast<const f32x4*>(c + k0);
+        if (UNIT) { xv = xv * rq; cv = cv * rc; }
         const f32x4 v = L2 ? xv - cv : xv;
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         nn = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], nn))));
@@ -153,6 +174,7 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(x + k0 + 4 * j);
+                if (UNIT) v = v * rq;
                 if (L2) v = v - *reinterpret_cast<const f32x4*>(c + k0 + 4 * j);
                 uint32_t word = 0;
 #pragma unroll
@@ -210,22 +232,31 @@ __global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __rest
 }
 
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xrow, unsigned* list_stats, hipStream_t s) {
+                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm, const float* cnorm) {
     if (rows <= 0) return;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(ivf_center_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow, list_stats);
+    if (xnorm && cnorm)
+        hipLaunchKernelGGL(ivf_center_shadow_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow,
+                           list_stats, xnorm, cnorm);
+    else
+        hipLaunchKernelGGL(ivf_center_shadow_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow,
+                           list_stats, (const float*)nullptr, (const float*)nullptr);
 }
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
                               const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,
-                              int metric) {
+                              int metric, const float* qnorm, const float* cnorm) {
     if (nslots <= 0) return;
+    const dim3 grid((unsigned)((nslots + 3) / 4)), block(256);
     if (metric == SC_METRIC_L2)
-        hipLaunchKernelGGL(ivf_pair_query_kernel<true>, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats,
-                           (int8_t*)Qc8, slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
+        hipLaunchKernelGGL((ivf_pair_query_kernel<true, false>), grid, block, 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8, slot_qs, slot_qnlb,
+                           slot_qb, slot_qd, slot_eps, (const float*)nullptr, (const float*)nullptr);
+    else if (metric == SC_METRIC_COSINE)
+        hipLaunchKernelGGL((ivf_pair_query_kernel<false, true>), grid, block, 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8, slot_qs, slot_qnlb,
+                           slot_qb, slot_qd, slot_eps, qnorm, cnorm);
     else
-        hipLaunchKernelGGL(ivf_pair_query_kernel<false>, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats,
-                           (int8_t*)Qc8, slot_qs, slot_qnlb, slot_qb, slot_qd, slot_eps);
+        hipLaunchKernelGGL((ivf_pair_query_kernel<false, false>), grid, block, 0, s, Qp, ld, ld8, C, ldc, slot_q, slot_l, nslots, list_stats, (int8_t*)Qc8, slot_qs, slot_qnlb,
+                           slot_qb, slot_qd, slot_eps, (const float*)nullptr, (const float*)nullptr);
 }
 void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
                             hipStream_t s) {
@@ -249,6 +280,7 @@ void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const
 int sc_ivf_widen_cap(void) { return IVFW_CAP; }
 
 static __device__ __forceinline__ float ivf_rounding_allowance(int metric, const unsigned* __restrict__ xmax_bits, float qnorm2, int ld) {
+    if (metric == SC_METRIC_COSINE) return ((float)ld * 1.2e-7f) * 1.01f + 1e-6f;  // scores of unit vectors (the certificate's relative form)
     const float xmax = sqrtf(__builtin_bit_cast(float, xmax_bits[0])), qn = sqrtf(qnorm2);
     return ((metric == SC_METRIC_L2 ? 2.0f : 1.0f) * (float)ld * 1.2e-7f * xmax * qn) * 1.01f + 1e-6f;
 }

@@ -168,10 +168,10 @@ void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int l
 
 // ivf_coarse.hip + scan_batched.hip: the int8 coarse stage of list-major IVF probing (L2)
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xrow, unsigned* list_stats, hipStream_t s);
+                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm = nullptr, const float* cnorm = nullptr);  // norms: COSINE
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
                               const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,
-                              int metric = SC_METRIC_L2);
+                              int metric = SC_METRIC_L2, const float* qnorm = nullptr, const float* cnorm = nullptr);
 void sc_launch_ivf_slot_thr(const int32_t* slot_q, const float* slot_qnlb, const float* slot_eps, const float* thr, int nslots, float* slot_thr, float* slot_tf,
                             hipStream_t s);
 void sc_launch_ivf_coarse(const void* Xc8, const float* xrow, int ld8, const void* Qc8, const void* items, int nitems, const float* slot_tf,

@@ -819,7 +819,7 @@ static int ivfc_ld8(const sc_index* ix) { return (ix->ld + 127) / 128 * 128; }
 
 bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
     static const bool env_off = [] { const char* e = getenv("SC_IVF_COARSE"); return e && e[0] == '0'; }();
-    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || !ix->perm || (ix->metric != SC_METRIC_L2 && ix->metric != SC_METRIC_IP)) return false;
+    if (ix->kind != SC_INDEX_IVF_FLAT || !ix->trained || !ix->quant || !ix->perm || (ix->metric != SC_METRIC_L2 && ix->metric != SC_METRIC_IP && ix->metric != SC_METRIC_COSINE)) return false;
     if (nprobe < 2 || nprobe > 512 || nprobe >= ix->nlist_trained || k < 1 || k > sc_batched_kprime8() / 2) return false;
     if (ix->search_mode == 5) return Q >= 1;
     if (ix->search_mode != 0 || env_off || ix->ivfc_off) return false;
@@ -843,7 +843,9 @@ static sc_status ivfc_ensure_shadow(sc_index* ix) {
     SC_HIP(hipMemsetAsync(ix->list_stats, 0, ((size_t)ix->nlist * 2 + 4) * 4, s));
     SC_HIP(hipMemsetAsync((char*)ix->Xc8 + (size_t)rows * ld8, 0, (size_t)(rows_pad - rows) * ld8, s));
     SC_HIP(hipMemsetAsync(ix->xcs + rows * 4, 0, (size_t)(rows_pad - rows) * 16, s));
-    sc_launch_ivf_center_shadow(ix->X, rows, ix->ld, ld8, ix->quant->X, ix->quant->ld, ix->list_off, nlist, ix->Xc8, ix->xcs, ix->list_stats, s);
+    const bool unit = ix->metric == SC_METRIC_COSINE;  // the IP form on normalised rows and centroids
+    sc_launch_ivf_center_shadow(ix->X, rows, ix->ld, ld8, ix->quant->X, ix->quant->ld, ix->list_off, nlist, ix->Xc8, ix->xcs, ix->list_stats, s,
+                                unit ? ix->xnorm : nullptr, unit ? ix->quant->xnorm : nullptr);
     sc_launch_norm_max(ix->xnorm, rows, ix->list_stats + (size_t)ix->nlist * 2, s);  // bits of max |x|^2: the re-rank's rounding allowance
     SC_HIP(hipGetLastError());
     ix->shadowc_rows = rows;
@@ -1029,8 +1031,9 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
     st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
     if (st) return st;
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
-    const int metric = (int)ix->metric;  // L2, or IP (rows centred only; ivf_coarse.hip)
-    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s, metric);
+    const int metric = (int)ix->metric;  // L2; IP (rows centred only); COSINE (the IP form on unit vectors) -- ivf_coarse.hip
+    const int kmetric = metric == SC_METRIC_COSINE ? (int)SC_METRIC_IP : metric;  // what the streaming kernel computes
+    sc_launch_ivf_pair_query(ix->qpad, ld, ld8, qz->X, qz->ld, d_sq, d_sl, nslots, ix->list_stats, b + o_qc, d_qs, d_qn, d_qb, d_qd, d_se, s, metric, ix->qnorm, qz->xnorm);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, kpa, s);
     // phase A is dense: every row of its lists survives, at a known place of survA; the counts are known here
     SC_HIP(hipMemcpyAsync(cnt, cntA.data(), (size_t)Q * 4, hipMemcpyHostToDevice, s));
@@ -1042,7 +1045,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);  // (+inf everywhere; the dense form tests nothing)
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items, (int)items[0].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survA, cnt, IVFC_CAP,
-                             b + o_hits, hit_bytes, s, d_sd, metric);
+                             b + o_hits, hit_bytes, s, d_sd, kmetric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
     }
     sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
@@ -1070,7 +1073,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + b_first * sizeof(Item), (int)items[1].size(), d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survB,
-                             cnt, IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, metric);
+                             cnt, IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, kmetric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         st = tighten();
         if (st) return st;
@@ -1081,7 +1084,7 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
         sc_launch_ivf_slot_thr(d_sq, d_qn, d_se, thr, nslots, d_st, d_stf, s);
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         sc_launch_ivf_coarse(ix->Xc8, ix->xcs, ld8, b + o_qc, b + o_items + b_first * sizeof(Item), (int)b_count, d_stf, d_st, d_qn, d_qs, d_sq, d_qb, d_qd, survB, cnt,
-                             IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, metric);
+                             IVFC_CAPB, b + o_hits, hit_bytes, s, nullptr, kmetric);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
     }
     if (two_level && b_count > 0) {  // ... and once more over everything phase B kept: a query between two clusters finds its neighbours in the other lists

@@ -378,11 +378,11 @@ def test_search_survives_a_refresh_that_cannot_get_its_memory(rt):
     ix.close()
 
 
-@pytest.mark.parametrize("metric", ["L2", "IP"])
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
 @pytest.mark.parametrize("dim,n,ncl,nlist", [(96, 30_000, 25, 64), (768, 40_000, 40, 64), (2048, 12_000, 20, 32)])
 def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist, metric):
     """List-major probing behind the int8 coarse stage (lists quantised relative to their centroids; L2: one centred query per (query,
-    list) pair, IP: the query itself plus the pair's <c, q>; coarse scores as bounds of the exact score; bound and refine;
+    list) pair, IP: the query itself plus the pair's <c, q>, COSINE: that form on unit vectors; coarse scores as bounds of the exact score; bound and refine;
     what it cannot hold probed again exactly) returns bit for bit what the exact list-major probe returns: tight and loose
     clusters, empty lists, lists longer than one row tile and wanted by more queries than one group of 64 slots, k up to 64, few
     workgroups walking many work items."""
@@ -461,7 +461,7 @@ def test_coarse_stage_without_room_for_its_shadow_leaves_the_exact_probe_in_char
     ix.close()
 
 
-@pytest.mark.parametrize("metric", ["L2", "IP"])
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
 def test_coarse_stage_with_lists_longer_than_its_survivor_lists(rt, metric):
     """The reference's own index parameters (nlist 128) put tens of thousands of rows into a list: phase A then takes a 4 096-row
     prefix of the nearest list (any subset bounds the k-th score) and the rest of that list joins phase B."""
@@ -485,7 +485,7 @@ def test_coarse_stage_with_lists_longer_than_its_survivor_lists(rt, metric):
     ix.close()
 
 
-@pytest.mark.parametrize("metric", ["L2", "IP"])
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
 def test_coarse_stage_survives_upserts_and_near_duplicates(rt, metric):
     """Rows upserted after the build are folded into the lists (refresh), which rebuilds the centred shadow.  700 near-duplicates of
     one row (gaps far below any int8 bound) all have lower bounds within reach of the k-th distance: the refine step re-scores them
