@@ -203,8 +203,9 @@ __global__ __launch_bounds__(256) void ivf_pair_query_kernel(const float* __rest
             slot_qd[slot] = dq * 1.01f;
             slot_eps[slot] = (2.0f * (dx * qn + (xm + dx) * dq)) * 1.03f + 1e-6f;  // >= the kernel's row-wise bound for every row of the list
         } else {
-            // rounding of the scaled integer dot and of <c, q> itself (an f32 tree sum here, not the canonical chain)
-            const float round_eps = (4.0e-6f * ((xm + dx) * qn + fabsf(cq)) + (float)ld * 2.4e-7f * (sqrtf(cn) + xm + dx) * qn) * 1.01f + 1e-6f;
+            // rounding of the scaled integer dot and of <c, q> itself: an f32 sum of ld / 64 fmas per lane, a 6-level tree over the lanes
+            // and 3 adds -- its error is below (ld / 64 + 9) 2^-24 sum |c_i q_i| <= ... |c| |q|; four times that is allowed for
+            const float round_eps = (4.0e-6f * ((xm + dx) * qn + fabsf(cq)) + (float)(ld / 64 + 16) * 2.4e-7f * (sqrtf(cn) + xm + dx) * qn) * 1.01f + 1e-6f;
             slot_qnlb[slot] = -(cq + round_eps);
             slot_qb[slot] = 0.5f * qn * 1.01f;
             slot_qd[slot] = 0.5f * dq * 1.01f;

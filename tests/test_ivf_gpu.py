@@ -392,7 +392,7 @@ def test_coarse_stage_probe_equals_exact_listmajor_probe(rt, dim, n, ncl, nlist,
     ix.add(X)
     ix.train(niter=5)
     try:
-        for nq, k, nprobe, wgs in ((2, 10, 2, 0), (70, 1, 4, 0), (200, 10, 16, 8), (333, 64, 7, 0), (40, 5, nlist - 1, 24)):
+        for nq, k, nprobe, wgs in ((2, 10, 2, 0), (70, 1, 4, 0), (200, 10, 16, 8), (333, 64, 7, 0), (40, 5, nlist - 1, 24), (90, 100, 9, 0)):  # k = 100: 512 re-scored for the bound
             Q = (centers[rng.integers(0, ncl, size=nq)] + 0.4 * rng.standard_normal((nq, dim))).astype(np.float32)
             ix.set_search_mode("ivf_listmajor")
             d4, r4 = ix.search(Q, k=k, nprobe=nprobe)
