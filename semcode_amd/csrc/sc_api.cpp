@@ -657,7 +657,8 @@ static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
     if (k > sc_batched_kprime() / 2 || ix->n < 1) return false;
     if (ix->search_mode == 2) return true;
-    return Q > 16 && ix->n >= 4096;
+    static const int64_t min_rows = [] { const char* e = getenv("SC_BATCHED_MINROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();  // A/B
+    return Q > 16 && ix->n >= min_rows;
 }
 
 // The int8 stage is tried first (twice the MFMA rate, half the shadow bytes); what it cannot certify goes to the bf16 stage, and
