@@ -198,7 +198,8 @@ sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t
  * of the persistent coarse-scan kernel (0 = one workgroup per CU), so that tests can make a few workgroups walk many tiles;
  * "coarse_persistent": 0 = one workgroup per tile instead; "gemm_pp": main loop of the 256-tile GEMMs (-1 default, 0 = one barrier
  * per K-tile, 2..5 = ping-pong with that many half-tiles in flight); "ivf_refresh_nomem": 1 = the re-layout of a trained IVF index
- * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "collect_pass": 0 = queries a
+ * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "tighten": 0 = the batched scan's thresholds stay the kp-th best coarse keys
+ * (no exact re-score of the 128 best before the large phases); "collect_pass": 0 = queries a
  * coarse stage cannot certify go straight to the next stage (no collect pass); "ivf_coarse_nomem": 1 = the IVF coarse stage
  * cannot allocate its centred shadow (the search must then probe exactly instead of failing); "ivf_refine_cap":
  * rows per query the IVF coarse stage's refine step takes on (-1 = default 4096; a small value sends queries to the exact re-probe). */

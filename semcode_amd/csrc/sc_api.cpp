@@ -674,6 +674,8 @@ static int coarse_env() {
     return v;
 }
 
+static int g_tighten = 1;  // sc_diag_set_option("tighten", 0): thresholds stay the kp-th coarse keys (tests, A/B)
+void sc_set_tighten(int v) { g_tighten = v; }
 static int g_collect_pass = 1;  // sc_diag_set_option("collect_pass", 0): uncertified queries go straight to the next stage (tests, A/B)
 void sc_set_collect_pass(int v) { g_collect_pass = v; }
 
@@ -752,7 +754,9 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     const size_t o_qres = carve((size_t)Q * 4), o_amax = carve(16);
     const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
-                 o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8);
+                 o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8),
+                 o_b128 = carve((size_t)Q * 128 * 8), o_e128 = carve((size_t)Q * 128 * 8), o_cut = carve((size_t)Qpad * 4), o_cnt2 = carve((size_t)Q * 4),
+                 o_thrT = carve((size_t)Qpad * 4), o_tfT = carve((size_t)Qpad * 4);
     // per-wave hit lists of the narrow int8 kernel (batches of <= 64 queries): 2048 lists x 1024 entries of 16 B
     const size_t hit_bytes = (i8 && Q <= 64) ? (size_t)2048 * (4 + 1024 * 16) + 256 : 0;
     const size_t o_hits = carve(hit_bytes ? hit_bytes : 16);
@@ -771,10 +775,32 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
     else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
+    // thresholds from exact scores before the large phases (scan_batched.hip, scan_tighten_kernel): from 2^19 rows seen on
+    static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
+    const bool tighten = tighten_env && g_tighten && 2 * k <= 128;
+    float* thr_cut = (float*)(b + o_cut);
+    bool cut_used = false;
+    if (tighten) sc_launch_fill_u32((unsigned*)thr_cut, 0x7F800000u, Qpad, s);  // +inf
     int64_t r0 = 0, span = phase0_rows();
     while (r0 < ix->n) {
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;
+        if (tighten && r0 >= ((int64_t)1 << 19)) {
+            uint64_t *b128 = (uint64_t*)(b + o_b128), *e128 = (uint64_t*)(b + o_e128);
+            unsigned* cnt2 = (unsigned*)(b + o_cnt2);
+            sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+            const uint64_t* from = best;
+            if (KP > 128) {  // the 128 best of the kp candidates (a selection over `best` as if it were a survivor list)
+                sc_launch_fill_u32(cnt2, (unsigned)KP, Q, s);
+                SC_HIP(hipMemsetAsync(b128, 0xFF, (size_t)Q * 128 * 8, s));
+                sc_launch_scan_select(metric, best, cnt2, KP, b128, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), ovf, Q, 128, s);
+                from = b128;
+            }
+            sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, from, nullptr, 128, ix->perm, e128, Q, s);
+            sc_launch_scan_tighten(metric, e128, 128, k, ix->qnorm, qres, i8 ? ix->xnorm_max8 : ix->xnorm_max, ld, thr, tf, thr_cut, Q, s);
+            sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+            cut_used = true;
+        }
         sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
         // a query keeps about KP of the r0 rows seen so far: a 256 x 256 tile of this phase about 65536 KP / r0 survivors -- above a few
         // hundred the two-pass epilogue (one list-slot atomic per query and tile instead of one per survivor)
@@ -788,6 +814,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         r0 = r1;
         span *= 4;
     }
+    if (cut_used) sc_launch_scan_thr_min(thr, thr_cut, Q, s);  // the certificate's threshold: no looser than any cut that was applied
     sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, i8 ? ix->xnorm_max8 : ix->xnorm_max, qres, ovf, Q, k, ix->row_base,
                           ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
     SC_HIP(hipGetLastError());

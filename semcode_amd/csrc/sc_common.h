@@ -186,6 +186,11 @@ void sc_launch_scan_rerank_keys(int metric, const float* X, const float* xnorm, 
 void sc_launch_scan_collect_bound(int metric, const float* prev_dist, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
                                   float* thr_fast, int* flags, int Q, hipStream_t s);
 void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, int* flags, int Q, hipStream_t s);
+// thresholds from exact scores before the large phases (scan_batched.hip): ekeys [Q][kp <= 128] exact keys of the best coarse candidates
+void sc_launch_scan_tighten(int metric, const uint64_t* ekeys, int kp, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
+                            float* thr_fast, float* thr_cut, int Q, hipStream_t s);
+void sc_launch_scan_thr_min(float* thr, const float* thr_cut, int Q, hipStream_t s);
+void sc_launch_fill_u32(unsigned* p, unsigned v, int n, hipStream_t s);
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
                                int Q, hipStream_t s);
 int sc_ivf_widen_cap(void);

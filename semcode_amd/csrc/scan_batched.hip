@@ -975,6 +975,67 @@ __global__ __launch_bounds__(256) void scan_collect_bound_kernel(const float* __
     thr_fast[q] = tf;
     flags[q] = ok ? 0 : 1;
 }
+// ---- thresholds from EXACT scores before the large phases ---------------------------------------------------------------------------
+// Between phases the threshold of a query is its kp-th best coarse key; a phase of 3 r0 new rows then yields 3 kp survivors per
+// query (kp = 512: 1 536), each of which costs the threshold epilogue a trip through its precise test -- 1.3 of the 7.9 ms of coarse
+// kernels per step, most of it in the last two phases (94 % of the rows).  But a row matters only if its coarse score is within
+// eps of the k-th EXACT score, and far fewer than kp rows are (~150 on the Gaussian benchmark: what the certificate needs kp = 512
+// for is the worst query, not the typical one).  So before a large phase the 128 best of the kp candidates are re-scored exactly
+// (0.4 GB of scattered rows) and the threshold becomes  min(kp-th coarse key, k-th exact score + eps (+ a hair))  -- eps is the
+// certificate's own bound, so the cut is one the certificate accepts: a row dropped by it has coarse > v_k + eps, i.e. exact > v_k.
+// thr_cut keeps the smallest cut ever applied to a query; the certificate compares with min(final kp-th key, thr_cut).
+template <int METRIC>
+__global__ __launch_bounds__(128) void scan_tighten_kernel(const uint64_t* __restrict__ ekeys, int kp, int k, const float* __restrict__ qnorm,
+                                                            const float* __restrict__ qres, const unsigned* __restrict__ bits, int ld,
+                                                            float* __restrict__ thr, float* __restrict__ thr_fast, float* __restrict__ thr_cut) {
+    __shared__ uint64_t keys[128];
+    __shared__ float s_v;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    keys[tid] = tid < kp ? ekeys[(size_t)q * kp + tid] : SC_KEY_MAX;
+    if (tid == 0) s_v = __builtin_inff();
+    __syncthreads();
+    const uint64_t key = keys[tid];
+    if (key != SC_KEY_MAX) {
+        int rank = 0;
+        for (int j = 0; j < 128; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
+        if (rank == k - 1) {
+            const float sc = sc_key_score(METRIC, key);
+            s_v = (METRIC == SC_METRIC_L2) ? sc : -sc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = thr[q];
+        const float vk = s_v;
+        if (vk < 3.0e38f) {
+            const float eps = certificate_eps<METRIC>(bits, qnorm[q], qres[q], ld);
+            const float cut = (vk + eps) + fabsf(vk + eps) * 2e-6f + 1e-30f;  // strictly above v_k + eps: the certificate's "<" must hold when v_k does not improve
+            t = fminf(t, cut);
+        }
+        t = fminf(t, thr_cut[q]);
+        thr_cut[q] = t;
+        thr[q] = t;
+        float tf = __builtin_inff();
+        if (t < __builtin_inff()) {  // scan_select_kernel's fast-test form of the same threshold
+            const float slack = 1e-3f * fabsf(t) + 1e-6f;
+            const float qn = qnorm[q];
+            if (METRIC == SC_METRIC_L2) tf = (t - qn) + slack + 1e-3f * fabsf(qn);
+            else if (METRIC == SC_METRIC_COSINE) tf = (t + slack) * sqrtf(qn) + 1e-5f * sqrtf(qn);
+            else tf = t + slack;
+        }
+        thr_fast[q] = tf;
+    }
+}
+// thr[q] = min(thr[q], thr_cut[q]) before the certificate (the last selection may have left +inf: fewer than kp keys)
+__global__ __launch_bounds__(256) void scan_thr_min_kernel(float* __restrict__ thr, const float* __restrict__ thr_cut, int Q) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < Q) thr[q] = fminf(thr[q], thr_cut[q]);
+}
+__global__ __launch_bounds__(256) void scan_fill_u32_kernel(unsigned* __restrict__ p, unsigned v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ __launch_bounds__(256) void scan_collect_counts_kernel(const unsigned* __restrict__ count, int cap, int* __restrict__ ncand, int* __restrict__ flags, int Q) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
@@ -1701,6 +1762,19 @@ void sc_launch_scan_collect_bound(int metric, const float* prev_dist, int k, con
     if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_L2>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
     else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_COSINE>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
     else hipLaunchKernelGGL(scan_collect_bound_kernel<SC_METRIC_IP>, grid, block, 0, s, prev_dist, k, qnorm, qres, bits, ld, thr, thr_fast, flags, Q);
+}
+void sc_launch_scan_tighten(int metric, const uint64_t* ekeys, int kp, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
+                            float* thr_fast, float* thr_cut, int Q, hipStream_t s) {
+    const dim3 grid((unsigned)Q), block(128);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_L2>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_COSINE>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
+    else hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_IP>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
+}
+void sc_launch_scan_thr_min(float* thr, const float* thr_cut, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(scan_thr_min_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, thr, thr_cut, Q);
+}
+void sc_launch_fill_u32(unsigned* p, unsigned v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(scan_fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
 }
 void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, int* flags, int Q, hipStream_t s) {
     hipLaunchKernelGGL(scan_collect_counts_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, count, cap, ncand, flags, Q);
