@@ -775,7 +775,8 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
     else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
     sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
-    // thresholds from exact scores before the large phases (scan_batched.hip, scan_tighten_kernel): from 2^19 rows seen on
+    // thresholds from exact scores before the large phases (scan_batched.hip, scan_tighten_kernel): from 2^17 rows seen on
+    // (10M x 768 x 1024, same box: from 2^19 8.45 ms per step, 2^17 8.38, 2^15 8.36; without 8.80)
     static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
     const bool tighten = tighten_env && g_tighten && 2 * k <= 128;
     float* thr_cut = (float*)(b + o_cut);
@@ -785,7 +786,8 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     while (r0 < ix->n) {
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;
-        if (tighten && r0 >= ((int64_t)1 << 19)) {
+        static const int64_t tighten_from = [] { const char* e = getenv("SC_TIGHTEN_FROM"); return e ? (int64_t)atoll(e) : ((int64_t)1 << 17); }();  // A/B
+        if (tighten && r0 >= tighten_from) {
             uint64_t *b128 = (uint64_t*)(b + o_b128), *e128 = (uint64_t*)(b + o_e128);
             unsigned* cnt2 = (unsigned*)(b + o_cnt2);
             sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
