@@ -199,7 +199,8 @@ sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t
  * "coarse_persistent": 0 = one workgroup per tile instead; "gemm_pp": main loop of the 256-tile GEMMs (-1 default, 0 = one barrier
  * per K-tile, 2..5 = ping-pong with that many half-tiles in flight); "ivf_refresh_nomem": 1 = the re-layout of a trained IVF index
  * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "tighten": 0 = the batched scan's thresholds stay the kp-th best coarse keys
- * (no exact re-score of the 128 best before the large phases); "collect_pass": 0 = queries a
+ * (no exact re-score of the 128 best before the large phases); "wide_candidates": 1 = the int8 stage keeps every key within its cut
+ * (the form it otherwise switches to on corpora whose certificate fails) wherever it can; "collect_pass": 0 = queries a
  * coarse stage cannot certify go straight to the next stage (no collect pass); "ivf_coarse_nomem": 1 = the IVF coarse stage
  * cannot allocate its centred shadow (the search must then probe exactly instead of failing); "ivf_refine_cap":
  * rows per query the IVF coarse stage's refine step takes on (-1 = default 4096; a small value sends queries to the exact re-probe). */
@@ -306,6 +307,9 @@ sc_status sc_index_last_coarse_stats(sc_index* ix, int32_t* first_stage_bits, in
  * precision with a fixed threshold (k-th exact score found + the coarse error bound) whose survivors are ALL re-scored exactly;
  * `tried` = such queries (summed over the stages), `resolved` = those it answered (the rest went on to the next stage). */
 sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, int32_t* resolved);
+/* 1 if the last batched search ran the int8 stage in its wide form: every key within the exact-score cut kept between the phases
+ * (up to 4 096 per query) instead of the 512 best -- what the stage switches to on corpora whose certificate fails (clusters). */
+sc_status sc_index_last_wide(sc_index* ix, int32_t* wide);
 
 /* After an IVF probe search: rows of the DISTINCT lists the batch probed (`unique_rows`: the algorithmic bytes of SURVEY.md 8d
  * config 5 = unique_rows * ld * 4), rows the scan kernel streamed (`streamed_rows`: list-major probing streams a list once per

@@ -37,7 +37,7 @@ for name, ncl, spread in (("gaussian", 0, 0.0), ("clustered 4096 x 0.5", 4096, 0
         rt.synchronize()
         dt = (time.perf_counter() - t0) / 3
         st = ix.last_search_stats()
-        print(f"{name:22s} stage setting {stage:2d}, first stage {'int8' if st.get('coarse_bits') == 8 else 'bf16'}: {dt * 1e3:8.2f} ms / batch   collect pass {st.get('collect_resolved', 0):4d} of "
+        print(f"{name:22s} stage setting {stage:2d}, first stage {'int8' if st.get('coarse_bits') == 8 else 'bf16'}{' (wide)' if st.get('wide') else '       '}: {dt * 1e3:8.2f} ms / batch   collect pass {st.get('collect_resolved', 0):4d} of "
               f"{st.get('collect_tried', 0):4d}   handed to bf16 {st.get('handed_to_bf16', 0):4d}   uncertified (exact scan) {st['uncertified']:4d}", flush=True)
     ix.close()
 rt.close()

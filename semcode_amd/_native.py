@@ -103,6 +103,7 @@ SIGNATURES = {
     "sc_index_set_coarse_stage": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sc_index_last_coarse_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_collect_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sc_index_last_wide": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sc_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -379,7 +380,9 @@ class Index:
         if path.value == 2:
             tried, resolved = C.c_int32(), C.c_int32()
             _check(lib().sc_index_last_collect_stats(self.handle, C.byref(tried), C.byref(resolved)))
-            out.update(coarse_bits=bits.value, handed_to_bf16=handed.value, collect_tried=tried.value, collect_resolved=resolved.value)
+            wide = C.c_int32()
+            _check(lib().sc_index_last_wide(self.handle, C.byref(wide)))
+            out.update(coarse_bits=bits.value, handed_to_bf16=handed.value, collect_tried=tried.value, collect_resolved=resolved.value, wide=bool(wide.value))
         return out
 
     def search_sharded(self, comm: "Comm", queries, k: int = 10, nprobe: int = 16) -> tuple[np.ndarray, np.ndarray]:

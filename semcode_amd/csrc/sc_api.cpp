@@ -479,6 +479,7 @@ extern "C" sc_status sc_index_fill_synthetic(sc_index* ix, int64_t n, uint64_t s
     ix->shadow_rows = 0;
     ix->shadow8_rows = 0;
     ix->i8_off = false;
+    ix->wide_i8 = false;
     ix->i8_sticky = false;
     ix->cost_i8_first = 0.0;
     ix->collect_off8 = ix->collect_off16 = false;
@@ -502,6 +503,7 @@ extern "C" sc_status sc_index_fill_synthetic_clustered(sc_index* ix, int64_t n, 
     ix->shadow_rows = 0;
     ix->shadow8_rows = 0;
     ix->i8_off = false;
+    ix->wide_i8 = false;
     ix->i8_sticky = false;
     ix->cost_i8_first = 0.0;
     ix->collect_off8 = ix->collect_off16 = false;
@@ -674,6 +676,8 @@ static int coarse_env() {
     return v;
 }
 
+static int g_wide_force = 0;  // sc_diag_set_option("wide_candidates", 1): the int8 stage runs its wide form wherever it can (tests)
+void sc_set_wide_force(int v) { g_wide_force = v; }
 static int g_tighten = 1;  // sc_diag_set_option("tighten", 0): thresholds stay the kp-th coarse keys (tests, A/B)
 void sc_set_tighten(int v) { g_tighten = v; }
 static int g_collect_pass = 1;  // sc_diag_set_option("collect_pass", 0): uncertified queries go straight to the next stage (tests, A/B)
@@ -742,6 +746,13 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     const int metric = (int)ix->metric, ld = ix->ld, KP = i8 ? sc_batched_kprime8() : sc_batched_kprime();
     const int ld8 = ld8_of(ix);
     const int Qpad = (i8 || Q > 128) ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches (always for the int8 stage)
+    // the wide candidate set (scan_batched.hip): on corpora whose certificate fails at kp candidates the int8 stage keeps every key
+    // within its exact-score cut -- needs the cuts (tightening: 2 k <= 128, a corpus beyond 2^17 rows) and 64 KiB of keys per query
+    static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
+    const bool tighten = tighten_env && g_tighten && 2 * k <= 128;
+    const int WB = BATCH_CAP;  // capacity of the wide set
+    const bool wide = i8 && tighten && (ix->wide_i8 || g_wide_force) && depth == 0 && Q <= 16384 && ix->n > ((int64_t)1 << 18);
+    const int KB = wide ? WB : KP;  // row stride of `best`
     sc_status st = i8 ? ensure_shadow8(ix) : ensure_shadow(ix);
     if (st) return st;
     st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ld * 4);
@@ -754,7 +765,8 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     const size_t o_qres = carve((size_t)Q * 4), o_amax = carve(16);
     const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
-                 o_best = carve((size_t)Q * KP * 8), o_ek = carve(i8 ? (size_t)Q * KP * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8),
+                 o_best = carve((size_t)Q * KB * 8), o_ek = carve(i8 ? (size_t)Q * KB * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8),
+                 o_nbest = carve((size_t)Q * 4), o_wcand = carve(wide ? (size_t)Q * WB * 8 : 16), o_wnc = carve((size_t)Q * 4),
                  o_b128 = carve((size_t)Q * 128 * 8), o_e128 = carve((size_t)Q * 128 * 8), o_cut = carve((size_t)Qpad * 4), o_cnt2 = carve((size_t)Q * 4),
                  o_thrT = carve((size_t)Qpad * 4), o_tfT = carve((size_t)Qpad * 4);
     // per-wave hit lists of the narrow int8 kernel (batches of <= 64 queries): 2048 lists x 1024 entries of 16 B
@@ -774,11 +786,12 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ld, ix->qnorm, s);
     if (i8) sc_launch_query_i8(ix->qpad, Q, Qpad, ld, ld8, Qb, qscale, qres, (unsigned*)(b + o_amax), s);
     else sc_launch_query_bf16(ix->qpad, Q, Qpad, ld, Qb, qres, s);
-    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, KP, s);
+    sc_launch_scan_batched_init(thr, tf, Qpad, best, cnt, ovf, Q, wide ? 0 : KP, s);  // (wide: `best` carries its own counts, no padding)
+    unsigned* nbest = (unsigned*)(b + o_nbest);
+    if (wide) SC_HIP(hipMemsetAsync(nbest, 0, (size_t)Q * 4, s));
+    ix->last_wide = wide ? 1 : 0;
     // thresholds from exact scores before the large phases (scan_batched.hip, scan_tighten_kernel): from 2^17 rows seen on
     // (10M x 768 x 1024, same box: from 2^19 8.45 ms per step, 2^17 8.38, 2^15 8.36; without 8.80)
-    static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
-    const bool tighten = tighten_env && g_tighten && 2 * k <= 128;
     float* thr_cut = (float*)(b + o_cut);
     bool cut_used = false;
     if (tighten) sc_launch_fill_u32((unsigned*)thr_cut, 0x7F800000u, Qpad, s);  // +inf
@@ -787,15 +800,18 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         const int64_t r1 = std::min(ix->n, r0 + span);
         hipEvent_t e0, e1;
         static const int64_t tighten_from = [] { const char* e = getenv("SC_TIGHTEN_FROM"); return e ? (int64_t)atoll(e) : ((int64_t)1 << 17); }();  // A/B
-        if (tighten && r0 >= tighten_from) {
+        // (wide form: a cut before every phase but the first -- nothing may be truncated at kp while keys within reach of the k-th exact
+        // score can still arrive; the first selection keeps all of its 2 048 rows)
+        if (tighten && r0 >= (wide ? (int64_t)1 : tighten_from)) {
             uint64_t *b128 = (uint64_t*)(b + o_b128), *e128 = (uint64_t*)(b + o_e128);
             unsigned* cnt2 = (unsigned*)(b + o_cnt2);
             sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
             const uint64_t* from = best;
             if (KP > 128) {  // the 128 best of the kp candidates (a selection over `best` as if it were a survivor list)
-                sc_launch_fill_u32(cnt2, (unsigned)KP, Q, s);
+                if (wide) SC_HIP(hipMemcpyAsync(cnt2, nbest, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
+                else sc_launch_fill_u32(cnt2, (unsigned)KP, Q, s);
                 SC_HIP(hipMemsetAsync(b128, 0xFF, (size_t)Q * 128 * 8, s));
-                sc_launch_scan_select(metric, best, cnt2, KP, b128, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), ovf, Q, 128, s);
+                sc_launch_scan_select(metric, best, cnt2, KB, b128, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), (int*)(b + o_wnc), Q, 128, s);
                 from = b128;
             }
             sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, from, nullptr, 128, ix->perm, e128, Q, s);
@@ -811,14 +827,28 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         else sc_launch_scan_coarse(metric, ix->Xb, ix->xnorm, r0, r1, ld, Qb, ix->qnorm, Q, Qpad, thr, tf, surv, cnt, BATCH_CAP, s, false, nullptr, nullptr, dense);
         sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
         sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-        sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
+        if (wide) sc_launch_scan_select_wide(metric, surv, cnt, BATCH_CAP, best, nbest, WB, cut_used ? KP : WB, ix->qnorm, thr, tf, thr_cut, ovf, Q, s);
+        else sc_launch_scan_select(metric, surv, cnt, BATCH_CAP, best, ix->qnorm, thr, tf, ovf, Q, KP, s);
         sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
         r0 = r1;
         span *= 4;
     }
     if (cut_used) sc_launch_scan_thr_min(thr, thr_cut, Q, s);  // the certificate's threshold: no looser than any cut that was applied
-    sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, i8 ? ix->xnorm_max8 : ix->xnorm_max, qres, ovf, Q, k, ix->row_base,
-                          ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
+    if (wide) {  // the keys within the final threshold, re-scored exactly; exact top-k; the certificate as a kernel of its own
+        uint64_t* wcand = (uint64_t*)(b + o_wcand);
+        int* wnc = (int*)(b + o_wnc);
+        hipEvent_t e0, e1;
+        sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+        sc_launch_scan_wide_compact(metric, best, nbest, WB, thr, wcand, wnc, Q, s);
+        sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, wcand, wnc, WB, ix->perm, ekeys, Q, s);
+        SC_HIP(hipMemsetAsync(flags, 0, (size_t)Q * 4, s));
+        sc_launch_refine_finalize(metric, ekeys, wnc, flags, k, ix->row_base, out_dist, out_rows, Q, s);
+        sc_launch_scan_wide_certify(metric, out_dist, k, ix->qnorm, qres, ix->xnorm_max8, ld, thr, ovf, flags, Q, s);
+        sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+    } else {
+        sc_launch_scan_rerank(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, best, thr, i8 ? ix->xnorm_max8 : ix->xnorm_max, qres, ovf, Q, k, ix->row_base,
+                              ix->perm, out_dist, out_rows, flags, s, KP, ekeys);
+    }
     SC_HIP(hipGetLastError());
     // uncertified queries: hand them to the next stage (int8 -> bf16 -> exact scan)
     std::vector<int> hflags(Q);
@@ -831,7 +861,12 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     if (i8) {
         // most of a real batch uncertified: this corpus does not quantise well enough (tight clusters, outlier dimensions) --
         // later searches start at the bf16 stage until the rows are replaced wholesale
-        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8 && !ix->i8_sticky) ix->i8_off = true;
+        // (first resort: the wide candidate set -- the next batch keeps every key within the exact-score cut; if that fails too, bf16)
+        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8 && !ix->i8_sticky) {
+            const bool wide_possible = tighten && Q <= 16384 && ix->n > ((int64_t)1 << 18);
+            if (!wide && wide_possible && !ix->wide_i8) ix->wide_i8 = true;
+            else ix->i8_off = true;
+        }
     }
     // second chance at this stage's precision: the collect pass (every row within the coarse error of the k-th exact score found)
     bool& collect_off = i8 ? ix->collect_off8 : ix->collect_off16;
@@ -1019,7 +1054,7 @@ extern "C" sc_status sc_index_set_coarse_stage(sc_index* ix, int32_t bits) {
     if (!ix || (bits != 0 && bits != 8 && bits != 16)) return sc_fail(SC_ERR_INVALID, "sc_index_set_coarse_stage: bits must be 0 (auto), 8 or 16");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->coarse_mode = bits;
-    if (bits == 0) { ix->i8_off = false; ix->i8_sticky = false; ix->cost_i8_first = 0.0; }
+    if (bits == 0) { ix->i8_off = false; ix->wide_i8 = false; ix->i8_sticky = false; ix->cost_i8_first = 0.0; }
     ix->collect_off8 = ix->collect_off16 = false;
     return SC_OK;
 }
@@ -1037,6 +1072,13 @@ extern "C" sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, i
     std::lock_guard<std::mutex> g(ix->mu);
     if (tried) *tried = ix->last_collect_tried;
     if (resolved) *resolved = ix->last_collect_resolved;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_wide(sc_index* ix, int32_t* wide) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (wide) *wide = ix->last_wide;
     return SC_OK;
 }
 

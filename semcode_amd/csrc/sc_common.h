@@ -190,6 +190,12 @@ void sc_launch_scan_collect_counts(const unsigned* count, int cap, int* ncand, i
 void sc_launch_scan_tighten(int metric, const uint64_t* ekeys, int kp, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, float* thr,
                             float* thr_fast, float* thr_cut, int Q, hipStream_t s);
 void sc_launch_scan_thr_min(float* thr, const float* thr_cut, int Q, hipStream_t s);
+// the wide candidate set (scan_batched.hip): best [Q][kcap] with nbest[q] keys, every key within thr_cut kept
+void sc_launch_scan_select_wide(int metric, const uint64_t* surv, unsigned* count, int cap, uint64_t* best, unsigned* nbest, int kcap, int kp, const float* qnorm,
+                                float* thr, float* thr_fast, const float* thr_cut, int* overflow, int Q, hipStream_t s);
+void sc_launch_scan_wide_compact(int metric, const uint64_t* best, const unsigned* nbest, int kcap, const float* thr, uint64_t* cand, int* ncand, int Q, hipStream_t s);
+void sc_launch_scan_wide_certify(int metric, const float* out_dist, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, const float* thr,
+                                 const int* overflow, int* flags, int Q, hipStream_t s);
 void sc_launch_fill_u32(unsigned* p, unsigned v, int n, hipStream_t s);
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
                                int Q, hipStream_t s);

@@ -73,6 +73,8 @@ struct sc_index {
     bool i8_off = false;                          // the int8 certificate failed for most of a batch on this corpus: use the bf16 stage
     int last_coarse_bits = 0;                     // 8 / 16: coarse stage of the last batched search
     int last_uncert_i8 = 0;                       // queries the int8 stage handed on to the bf16 stage
+    bool wide_i8 = false;                         // ... or rather: the int8 stage keeps EVERY key within its exact-score cut (up to 4 096 per query) -- tried before i8_off
+    int last_wide = 0;                            // the last batched search ran the wide form
     bool i8_sticky = false;                       // ... but the bf16-first batch that followed cost more: int8 first from now on (search_batched_locked)
     double cost_i8_first = 0.0;                   // seconds per query of the batch that switched the int8 stage off (0 = none pending)
     bool collect_off8 = false, collect_off16 = false;  // the collect pass of that stage resolved less than half of a sub-batch: skip it on this corpus

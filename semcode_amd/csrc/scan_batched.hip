@@ -1026,6 +1026,158 @@ __global__ __launch_bounds__(128) void scan_tighten_kernel(const uint64_t* __res
         thr_fast[q] = tf;
     }
 }
+// ---- the wide candidate set (corpora whose certificate fails at kp candidates: clusters) ----------------------------------------------
+// With thresholds from exact scores the selection between phases need not truncate at kp: it keeps EVERY key within the cut (up to
+// kcap = 4 096) and at least the kp best.  Nothing within the coarse error of the k-th exact score is ever dropped then, so the
+// certificate holds by construction and the batch is answered in this one pass -- where the kp-candidate form sent a clustered
+// batch through a second pass (the collect pass) or to the bf16 stage.  best [Q][kcap] holds nbest[q] keys (no padding).
+template <int METRIC>
+__global__ __launch_bounds__(SEL_THREADS) void scan_select_wide_kernel(const uint64_t* __restrict__ surv, unsigned* __restrict__ count, int cap,
+                                                                        uint64_t* __restrict__ best, unsigned* __restrict__ nbest, int kcap, int kp,
+                                                                        const float* __restrict__ qnorm, float* __restrict__ thr, float* __restrict__ thr_fast,
+                                                                        const float* __restrict__ thr_cut, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sel_lds[];  // [cap + kcap] candidates | hist[SEL_BINS] | scan[SEL_THREADS] | misc
+    uint64_t* cand = sel_lds;
+    unsigned* hist = reinterpret_cast<unsigned*>(sel_lds + cap + kcap);
+    unsigned* part = hist + SEL_BINS;
+    unsigned* misc = part + SEL_THREADS;  // [0] n, [1] chosen bin, [2] rank inside it, [3] output cursor, [4] keys within the cut
+    const int q = blockIdx.x, tid = threadIdx.x;
+    unsigned c = count[q];
+    if (c > (unsigned)cap) {
+        if (tid == 0) overflow[q] = 1;
+        c = cap;
+    }
+    const unsigned nb = nbest[q];
+    const float cutv = thr_cut[q];
+    const bool have_cut = cutv < __builtin_inff();
+    if (tid == 0) { misc[0] = 0; misc[3] = 0; misc[4] = 0; }
+    __syncthreads();
+    for (unsigned i = tid; i < c + nb; i += SEL_THREADS) {
+        const uint64_t key = i < c ? surv[(size_t)q * cap + i] : best[(size_t)q * kcap + (i - c)];
+        if (key == SC_KEY_MAX) continue;
+        cand[atomicAdd(&misc[0], 1u)] = key;
+        if (have_cut) {
+            const float sc = sc_key_score(METRIC, key);
+            if (((METRIC == SC_METRIC_L2) ? sc : -sc) <= cutv) atomicAdd(&misc[4], 1u);
+        }
+    }
+    __syncthreads();
+    const int n = (int)misc[0];
+    const int cle = (int)misc[4];
+    if (cle > kcap && tid == 0) overflow[q] = 1;  // more keys within the cut than the set holds: the query goes on to the next stage
+    const int keep = (n < kp ? n : kp) > (cle < kcap ? cle : kcap) ? (n < kp ? n : kp) : (cle < kcap ? cle : kcap);
+    uint64_t pivot = SC_KEY_MAX;  // keep every key <= pivot
+    if (n > keep) {
+        uint64_t prefix = 0;
+        unsigned want = (unsigned)(keep - 1);
+        for (int shift = 52; shift >= -8; shift -= 12) {
+            const int sh = shift < 0 ? 0 : shift;
+            const int bits = shift < 0 ? 4 : 12;
+            const unsigned mask = (1u << bits) - 1u;
+            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            const int hi_shift = sh + bits;
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const uint64_t key = cand[i];
+                if (hi_shift >= 64 || (key >> hi_shift) == prefix) atomicAdd(&hist[(unsigned)(key >> sh) & mask], 1u);
+            }
+            __syncthreads();
+            unsigned local = 0;
+            for (int j = 0; j < SEL_BINS / SEL_THREADS; ++j) local += hist[tid * (SEL_BINS / SEL_THREADS) + j];
+            unsigned incl = local;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(incl, off, 64);
+                if ((tid & 63) >= off) incl += o;
+            }
+            if ((tid & 63) == 63) part[tid >> 6] = incl;
+            __syncthreads();
+            unsigned pre = incl - local;
+            for (int w = 0; w < (tid >> 6); ++w) pre += part[w];
+            if (pre <= want && want < pre + local) {
+                unsigned acc = pre;
+                int bin = tid * (SEL_BINS / SEL_THREADS);
+                for (;; ++bin) {
+                    if (acc + hist[bin] > want) break;
+                    acc += hist[bin];
+                }
+                misc[1] = (unsigned)bin;
+                misc[2] = want - acc;
+            }
+            __syncthreads();
+            prefix = (prefix << bits) | (uint64_t)misc[1];
+            want = misc[2];
+            __syncthreads();
+        }
+        pivot = prefix;
+    }
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint64_t key = cand[i];
+        if (key <= pivot) best[(size_t)q * kcap + atomicAdd(&misc[3], 1u)] = key;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        nbest[q] = misc[3];  // == keep
+        count[q] = 0;
+        // what the rows dropped here (and by the phase's own test) exceed: the cut when every key within it was kept, else the kp-th key
+        float t = __builtin_inff();
+        if (have_cut && cle >= kp && cle <= kcap) t = cutv;
+        else if (n > keep && keep >= kp) {
+            const float sc = sc_key_score(METRIC, pivot);
+            t = (METRIC == SC_METRIC_L2) ? sc : -sc;
+        } else if (n == keep && keep >= kp && n == kp) {  // exactly kp keys: all stay, the threshold is their maximum (as scan_select_kernel has it)
+            uint64_t m = 0;
+            for (int i = 0; i < n; ++i) m = cand[i] > m ? cand[i] : m;
+            const float sc = sc_key_score(METRIC, m);
+            t = (METRIC == SC_METRIC_L2) ? sc : -sc;
+        }
+        float tf = __builtin_inff();
+        if (t < __builtin_inff()) {
+            const float slack = 1e-3f * fabsf(t) + 1e-6f;
+            const float qn = qnorm[q];
+            if (METRIC == SC_METRIC_L2) tf = (t - qn) + slack + 1e-3f * fabsf(qn);
+            else if (METRIC == SC_METRIC_COSINE) tf = (t + slack) * sqrtf(qn) + 1e-5f * sqrtf(qn);
+            else tf = t + slack;
+        }
+        thr[q] = t;
+        thr_fast[q] = tf;
+    }
+}
+// the keys of best within the final threshold, compacted: what the exact re-score has to look at
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_wide_compact_kernel(const uint64_t* __restrict__ best, const unsigned* __restrict__ nbest, int kcap,
+                                                                 const float* __restrict__ thr, uint64_t* __restrict__ cand, int* __restrict__ ncand) {
+    __shared__ unsigned s_n;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const unsigned nb = nbest[q];
+    const float tau = thr[q];
+    for (unsigned i = tid; i < nb; i += 256) {
+        const uint64_t key = best[(size_t)q * kcap + i];
+        const float sc = sc_key_score(METRIC, key);
+        if (((METRIC == SC_METRIC_L2) ? sc : -sc) <= tau) cand[(size_t)q * kcap + atomicAdd(&s_n, 1u)] = key;
+    }
+    __syncthreads();
+    if (tid == 0) ncand[q] = (int)s_n;
+}
+// the certificate of the wide form: the k-th exact score (out_dist, already final) + eps below the threshold, or nothing was ever dropped
+template <int METRIC>
+__global__ __launch_bounds__(256) void scan_wide_certify_kernel(const float* __restrict__ out_dist, int k, const float* __restrict__ qnorm, const float* __restrict__ qres,
+                                                                 const unsigned* __restrict__ bits, int ld, const float* __restrict__ thr,
+                                                                 const int* __restrict__ overflow, int* __restrict__ flags, int Q) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    int bad = overflow[q];
+    const float tau = thr[q];
+    if (tau < __builtin_inff()) {
+        const float d = out_dist[(size_t)q * k + (k - 1)];
+        const float vk = (METRIC == SC_METRIC_L2) ? d : -d;
+        if (!(vk + certificate_eps<METRIC>(bits, qnorm[q], qres[q], ld) < tau)) bad = 1;
+    }
+    flags[q] = bad;
+}
+
 // thr[q] = min(thr[q], thr_cut[q]) before the certificate (the last selection may have left +inf: fewer than kp keys)
 __global__ __launch_bounds__(256) void scan_thr_min_kernel(float* __restrict__ thr, const float* __restrict__ thr_cut, int Q) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -1769,6 +1921,33 @@ void sc_launch_scan_tighten(int metric, const uint64_t* ekeys, int kp, int k, co
     if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_L2>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
     else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_COSINE>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
     else hipLaunchKernelGGL(scan_tighten_kernel<SC_METRIC_IP>, grid, block, 0, s, ekeys, kp, k, qnorm, qres, bits, ld, thr, thr_fast, thr_cut);
+}
+void sc_launch_scan_select_wide(int metric, const uint64_t* surv, unsigned* count, int cap, uint64_t* best, unsigned* nbest, int kcap, int kp, const float* qnorm,
+                                float* thr, float* thr_fast, const float* thr_cut, int* overflow, int Q, hipStream_t s) {
+    const size_t lds = (size_t)(cap + kcap) * 8 + (SEL_BINS + SEL_THREADS + 8) * 4;
+    static ScDeviceOnce once;
+    sc_device_once(once, [&] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_wide_kernel<SC_METRIC_IP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_wide_kernel<SC_METRIC_L2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(scan_select_wide_kernel<SC_METRIC_COSINE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const dim3 grid((unsigned)Q), block(SEL_THREADS);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_select_wide_kernel<SC_METRIC_L2>, grid, block, lds, s, surv, count, cap, best, nbest, kcap, kp, qnorm, thr, thr_fast, thr_cut, overflow);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_select_wide_kernel<SC_METRIC_COSINE>, grid, block, lds, s, surv, count, cap, best, nbest, kcap, kp, qnorm, thr, thr_fast, thr_cut, overflow);
+    else hipLaunchKernelGGL(scan_select_wide_kernel<SC_METRIC_IP>, grid, block, lds, s, surv, count, cap, best, nbest, kcap, kp, qnorm, thr, thr_fast, thr_cut, overflow);
+}
+void sc_launch_scan_wide_compact(int metric, const uint64_t* best, const unsigned* nbest, int kcap, const float* thr, uint64_t* cand, int* ncand, int Q, hipStream_t s) {
+    const dim3 grid((unsigned)Q), block(256);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_wide_compact_kernel<SC_METRIC_L2>, grid, block, 0, s, best, nbest, kcap, thr, cand, ncand);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_wide_compact_kernel<SC_METRIC_COSINE>, grid, block, 0, s, best, nbest, kcap, thr, cand, ncand);
+    else hipLaunchKernelGGL(scan_wide_compact_kernel<SC_METRIC_IP>, grid, block, 0, s, best, nbest, kcap, thr, cand, ncand);
+}
+void sc_launch_scan_wide_certify(int metric, const float* out_dist, int k, const float* qnorm, const float* qres, const unsigned* bits, int ld, const float* thr,
+                                 const int* overflow, int* flags, int Q, hipStream_t s) {
+    const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
+    if (metric == SC_METRIC_L2) hipLaunchKernelGGL(scan_wide_certify_kernel<SC_METRIC_L2>, grid, block, 0, s, out_dist, k, qnorm, qres, bits, ld, thr, overflow, flags, Q);
+    else if (metric == SC_METRIC_COSINE) hipLaunchKernelGGL(scan_wide_certify_kernel<SC_METRIC_COSINE>, grid, block, 0, s, out_dist, k, qnorm, qres, bits, ld, thr, overflow, flags, Q);
+    else hipLaunchKernelGGL(scan_wide_certify_kernel<SC_METRIC_IP>, grid, block, 0, s, out_dist, k, qnorm, qres, bits, ld, thr, overflow, flags, Q);
 }
 void sc_launch_scan_thr_min(float* thr, const float* thr_cut, int Q, hipStream_t s) {
     hipLaunchKernelGGL(scan_thr_min_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, thr, thr_cut, Q);

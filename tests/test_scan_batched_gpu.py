@@ -253,3 +253,36 @@ def test_full_size_batched_1024_queries_over_10m(rt):
     de, re_ = ix.search(Q[sel], k=K)
     assert np.array_equal(re_, r[sel]) and np.array_equal(bits(de), bits(d[sel]))
     ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+def test_wide_candidate_set_answers_clustered_batches_in_one_pass(rt, metric):
+    """The int8 stage in its wide form (every key within the exact-score cut kept between the phases, the certificate by
+    construction): a clustered corpus of 400k rows whose clusters hold more rows than the 512 candidates of the plain form; same bits
+    as the exact scan, no query left over, no collect pass."""
+    n, dim, ncl = 400_000, 64, 300
+    ix = _native.Index(rt, dim, metric=metric)
+    ix.fill_synthetic_clustered(n, seed=3, nclusters=ncl, spread=0.05)
+    qs = _native.Index(rt, dim, metric=metric)
+    qs.fill_synthetic_clustered(96, seed=3, nclusters=ncl, spread=0.05, first_row=n + 999)
+    Q = qs.get_rows(0, 96)
+    qs.close()
+    try:
+        ix.set_search_mode("exact")
+        d0, r0 = ix.search(Q, k=10)
+        ix.set_search_mode("batched")
+        ix.set_coarse_stage(8)
+        _native.diag_set_option("wide_candidates", 1)
+        d1, r1 = ix.search(Q, k=10)
+        st = ix.last_search_stats()
+        assert st["path"] == "batched" and st["coarse_bits"] == 8 and st["wide"], st
+        assert np.array_equal(r0, r1) and np.array_equal(bits(d0), bits(d1)), st
+        assert st["uncertified"] == 0 and st["collect_tried"] == 0, st
+        _native.diag_set_option("wide_candidates", 0)
+        d2, r2 = ix.search(Q, k=10)  # the plain form: its certificate fails, the collect pass (or the exact scan) answers
+        st2 = ix.last_search_stats()
+        assert not st2["wide"] and st2["collect_tried"] + st2["uncertified"] >= 48, st2
+        assert np.array_equal(r0, r2) and np.array_equal(bits(d0), bits(d2))
+    finally:
+        _native.diag_set_option("wide_candidates", 0)
+        ix.close()
