@@ -365,13 +365,13 @@ __global__ __launch_bounds__(256) void ivf_candidates_kernel(int metric, const u
 // exact keys of the kpa + ncand[q] re-scored rows -> the k best, in order (flagged queries are left to the exact probe)
 __global__ __launch_bounds__(256) void ivf_refine_finalize_kernel(int metric, const uint64_t* __restrict__ ekeysA, int kpa, const uint64_t* __restrict__ ekeys,
                                                                    const int* __restrict__ ncand, const int* __restrict__ flags, int k, int64_t row_base,
-                                                                   float* __restrict__ out_dist, int64_t* __restrict__ out_rows) {
+                                                                   float* __restrict__ out_dist, int64_t* __restrict__ out_rows, int stride) {
     __shared__ uint64_t keys[IVFW_CAP + 512];
     __shared__ uint64_t wmin[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (flags[q]) return;
     const int n = kpa + ncand[q];
-    for (int i = tid; i < n; i += 256) keys[i] = i < kpa ? ekeysA[(size_t)q * kpa + i] : ekeys[(size_t)q * IVFW_CAP + (i - kpa)];
+    for (int i = tid; i < n; i += 256) keys[i] = i < kpa ? ekeysA[(size_t)q * kpa + i] : ekeys[(size_t)q * stride + (i - kpa)];
     __syncthreads();
     for (int j = 0; j < k; ++j) {
         uint64_t m = SC_KEY_MAX;
@@ -414,11 +414,11 @@ void sc_launch_ivf_candidates(int metric, const uint64_t* survA, const unsigned*
 }
 void sc_launch_ivf_refine_finalize(int metric, const uint64_t* ekeysA, int kpa, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base,
                                    float* out_dist, int64_t* out_rows, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows);
+    hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, ekeysA, kpa, ekeys, ncand, flags, k, row_base, out_dist, out_rows, IVFW_CAP);
 }
-// the same for the exhaustive path's collect pass (scan_batched.hip): ekeys [Q][sc_ivf_widen_cap()], any metric, no pre-scored block
+// the same for the exhaustive path (collect pass, wide / compacted final step; scan_batched.hip): ekeys [Q][stride] (0: sc_ivf_widen_cap()), any metric, no pre-scored block
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
-                               int Q, hipStream_t s) {
+                               int Q, hipStream_t s, int stride) {
     hipLaunchKernelGGL(ivf_refine_finalize_kernel, dim3((unsigned)Q), dim3(256), 0, s, metric, (const uint64_t*)nullptr, 0, ekeys, ncand, flags, k, row_base, out_dist,
-                       out_rows);
+                       out_rows, stride > 0 ? stride : IVFW_CAP);
 }

@@ -766,7 +766,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     const size_t o_qb = carve(i8 ? (size_t)Qpad * ld8 : (size_t)Qpad * ld * 2), o_qs = carve((size_t)Qpad * 4), o_thr = carve((size_t)Qpad * 4),
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
                  o_best = carve((size_t)Q * KB * 8), o_ek = carve(i8 ? (size_t)Q * KB * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8),
-                 o_nbest = carve((size_t)Q * 4), o_wcand = carve(wide ? (size_t)Q * WB * 8 : 16), o_wnc = carve((size_t)Q * 4),
+                 o_nbest = carve((size_t)Q * 4), o_wcand = carve((size_t)Q * KB * 8), o_wnc = carve((size_t)Q * 4),
                  o_b128 = carve((size_t)Q * 128 * 8), o_e128 = carve((size_t)Q * 128 * 8), o_cut = carve((size_t)Qpad * 4), o_cnt2 = carve((size_t)Q * 4),
                  o_thrT = carve((size_t)Qpad * 4), o_tfT = carve((size_t)Qpad * 4);
     // per-wave hit lists of the narrow int8 kernel (batches of <= 64 queries): 2048 lists x 1024 entries of 16 B
@@ -834,15 +834,20 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         span *= 4;
     }
     if (cut_used) sc_launch_scan_thr_min(thr, thr_cut, Q, s);  // the certificate's threshold: no looser than any cut that was applied
-    if (wide) {  // the keys within the final threshold, re-scored exactly; exact top-k; the certificate as a kernel of its own
+    // (the plain form can take the same final step over its kp slots -- SC_FINAL_COMPACT=1 -- but gains nothing from it: on the Gaussian
+    // benchmark ~200 of the 512 lie within the final threshold, and the step measures 8.47 ms either way)
+    static const bool compact_env = [] { const char* e = getenv("SC_FINAL_COMPACT"); return e && e[0] == '1'; }();
+    const bool compact_final = !wide && i8 && cut_used && compact_env;
+    if (wide || compact_final) {  // the keys within the final threshold, re-scored exactly; exact top-k; the certificate as a kernel of its own
         uint64_t* wcand = (uint64_t*)(b + o_wcand);
         int* wnc = (int*)(b + o_wnc);
         hipEvent_t e0, e1;
         sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
-        sc_launch_scan_wide_compact(metric, best, nbest, WB, thr, wcand, wnc, Q, s);
-        sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, wcand, wnc, WB, ix->perm, ekeys, Q, s);
+        if (!wide) sc_launch_fill_u32(nbest, (unsigned)KP, Q, s);
+        sc_launch_scan_wide_compact(metric, best, nbest, KB, thr, wcand, wnc, Q, s);
+        sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, wcand, wnc, KB, ix->perm, ekeys, Q, s);
         SC_HIP(hipMemsetAsync(flags, 0, (size_t)Q * 4, s));
-        sc_launch_refine_finalize(metric, ekeys, wnc, flags, k, ix->row_base, out_dist, out_rows, Q, s);
+        sc_launch_refine_finalize(metric, ekeys, wnc, flags, k, ix->row_base, out_dist, out_rows, Q, s, KB);
         sc_launch_scan_wide_certify(metric, out_dist, k, ix->qnorm, qres, ix->xnorm_max8, ld, thr, ovf, flags, Q, s);
         sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
     } else {

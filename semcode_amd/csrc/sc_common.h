@@ -198,7 +198,7 @@ void sc_launch_scan_wide_certify(int metric, const float* out_dist, int k, const
                                  const int* overflow, int* flags, int Q, hipStream_t s);
 void sc_launch_fill_u32(unsigned* p, unsigned v, int n, hipStream_t s);
 void sc_launch_refine_finalize(int metric, const uint64_t* ekeys, const int* ncand, const int* flags, int k, int64_t row_base, float* out_dist, int64_t* out_rows,
-                               int Q, hipStream_t s);
+                               int Q, hipStream_t s, int stride = 0);
 int sc_ivf_widen_cap(void);
 void sc_launch_ivf_bound(int metric, const uint64_t* ekeysA, int kpa, int k, const float* qnorm, const unsigned* xmax_bits, int ld, float* thr, int Q, hipStream_t s,
                          const uint64_t* ekeysT = nullptr, bool keep_min = false);

@@ -1155,6 +1155,7 @@ __global__ __launch_bounds__(256) void scan_wide_compact_kernel(const uint64_t* 
     const float tau = thr[q];
     for (unsigned i = tid; i < nb; i += 256) {
         const uint64_t key = best[(size_t)q * kcap + i];
+        if (key == SC_KEY_MAX) continue;  // (the plain form pads its kp slots)
         const float sc = sc_key_score(METRIC, key);
         if (((METRIC == SC_METRIC_L2) ? sc : -sc) <= tau) cand[(size_t)q * kcap + atomicAdd(&s_n, 1u)] = key;
     }
