@@ -997,7 +997,7 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         }
         if (rst) return rst;
     }
-    if (sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    if (!sc_ivf_coarse_applicable(ix, Q, k, nprobe) && sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     if (sc_ivf_coarse_applicable(ix, Q, k, nprobe)) {
         // per-query scratch of the coarse stage is ~200 KB (two survivor lists of 8 192 keys, the refine sets): very large batches go
         // through it in chunks of 4 096 queries (0.8 GB), each a full batch of its own

@@ -823,8 +823,17 @@ bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
     if (nprobe < 2 || nprobe > 512 || nprobe >= ix->nlist_trained || k < 1 || k > sc_batched_kprime8() / 2) return false;
     if (ix->search_mode == 5) return Q >= 1;
     if (ix->search_mode != 0 || env_off || ix->ivfc_off) return false;
-    // auto: batches for which list-major probing would be chosen (every list wanted by several queries)
-    return Q >= 64 && (int64_t)Q * nprobe >= ix->nlist_trained && ix->n >= 100000;
+    // auto: any batch over a corpus worth a shadow.  The first rule here (Q >= 64 and Q nprobe >= nlist: "every list wanted by several
+    // queries") was list-major thinking -- the stage's gain is the int8 bytes, not the sharing: at config 5 a batch of 32 queries
+    // takes 22.9 ms through the per-query probe, 4.9 ms list-major exact and 1.9 ms here; of 2 queries 1.5 / 1.4 / 0.7 ms
+    // (scripts/ivf_small_batch.py, profiles/r3z_ivf_small_batch*.log).  Fewer than 8 queries take it when ONE probe would stream a
+    // gigabyte of f32 rows or more (config 5, one query: 0.50 ms against 0.83 through the per-query probe; 10M x 768 at the
+    // reference's nlist 128 / nprobe 16: 0.51 against 0.67); below that the plan's round trip to the host costs more than the
+    // bytes saved (1M x 768, 2 queries: 0.32 ms against 0.14).
+    if (ix->n < 100000) return false;
+    if (Q >= 8) return true;
+    const double probed_bytes = (double)nprobe * ((double)ix->n / (double)ix->nlist_trained) * (double)ix->ld * 4.0;
+    return probed_bytes >= 1.0e9;
 }
 
 static int g_ivfc_nomem = 0;  // sc_diag_set_option("ivf_coarse_nomem", 1): the centred shadow cannot be allocated (tests of the fallback to the exact probe)
