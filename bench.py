@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric-type", default="L2", choices=["L2", "IP", "COSINE"])
+    ap.add_argument("--search-mode", default="auto", choices=["auto", "exact", "batched"], help="scan: path of the timed step (exact: the f32 scan kernel whatever the batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="scan: skip the Q in {1, 16, 32, 256} sweep (SURVEY 8d: report 1, 32, 256, 1024; 16 is the exact kernel's largest single pass)")
     ap.add_argument("--sweep", action="store_true", help="(default now; kept for old command lines)")
@@ -233,6 +234,8 @@ def bench_scan(ctx, args) -> dict:
     rt, dev, world, rank = ctx.rt, ctx.dev, ctx.world, ctx.rank
     ix = _native.Index(rt, dim, metric=args.metric_type, kind="FLAT", row_base=rank * rows)
     ix.fill_synthetic(rows, seed=0, first_row=rank * rows)  # shard r = rows [r*rows, (r+1)*rows) of ONE global corpus
+    if args.search_mode != "auto":
+        ix.set_search_mode(args.search_mode)
     q = torch.empty((Q, dim), dtype=torch.float32, device=dev)
     rt.synth_fill_dev(q.data_ptr(), Q, dim, dim, seed=1)
     out_d = torch.empty((Q, k), dtype=torch.float32, device=dev)
@@ -318,9 +321,12 @@ def bench_scan(ctx, args) -> dict:
     sweep, exact_roof = None, None
     if not args.no_sweep:
         sweep = []
-        for nq in (1, 16, 32, 256):
+        # (1 and 16 queries also with the exact f32 scan forced: the HBM roofline block below is that kernel's; the planner itself
+        # answers such batches through the int8 narrow kernel where an int8 shadow may exist)
+        for nq, mode in ((1, "auto"), (16, "auto"), (32, "auto"), (256, "auto"), (1, "exact"), (16, "exact")):
             if nq > Q:
                 continue
+            ix.set_search_mode(mode)
             for _ in range(2):
                 step(nq)
             rt.set_profiling(True)
@@ -334,7 +340,7 @@ def bench_scan(ctx, args) -> dict:
             # (batched path: int8 = 1 B, bf16 = 2 B per padded element)
             ldq = (dim + 63) // 64 * 64
             streamed = rows * ldq * 4 * ((nq + 15) // 16) if p == "exact" else rows * ((ldq + 127) // 128 * 128 if stq.get("coarse_bits", 16) == 8 else ldq * 2)
-            sweep.append({"queries": nq, "path": p, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps * world / t,
+            sweep.append({"queries": nq, "mode": mode, "path": p, "ms_per_batch": 1e3 * t / args.steps, "qps": nq * args.steps * world / t,
                           "scan_kernel_ms_per_batch": k_ms / args.steps,
                           "algorithmic_f32_gbs": rows * dim * 4 / (t / args.steps) / 1e9,  # SURVEY 8d's figure (f32 shard once per batch), NOT a memory rate
                           "streamed_gbs": streamed / (t / args.steps) / 1e9, "streamed_bytes_per_batch": streamed})
@@ -347,6 +353,7 @@ def bench_scan(ctx, args) -> dict:
                         "traffic_note": f"HBM-side bytes per launch, {(pmc_traffic() or {}).get('_file')} (one corpus pass; f32 shard = rows*dim*4)"}
                 if exact_roof is None or nq == 1:
                     exact_roof = cand
+        ix.set_search_mode("auto")
     ix.close()
 
     # The same batch on CLUSTERED corpora (4 096 Gaussian clusters: what code embeddings look like more than i.i.d. rows do).

@@ -17,7 +17,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_f"
 echo "pmc fetch done"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_w" -o w -- python3 bench.py $PMC_ARGS > "$out/pmc_w.log" 2>&1
 echo "pmc write done"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_e" -o e -- python3 bench.py --workload scan --queries 16 $PMC_ARGS > "$out/pmc_e.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_e" -o e -- python3 bench.py --workload scan --queries 16 --search-mode exact $PMC_ARGS > "$out/pmc_e.log" 2>&1
 echo "pmc exact done"
 if timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$out/pmc_m" -o m -- python3 bench.py $PMC_ARGS > "$out/pmc_m.log" 2>&1; then
     python3 scripts/pmc_mfma_summary.py --csv "$(find "$out/pmc_m" -name '*counter_collection.csv' | head -1)" --out "$out/${tag}_pmc_mfma.json" > /dev/null && echo "pmc mfma done"

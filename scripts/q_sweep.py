@@ -13,6 +13,9 @@ rt = _native.Runtime(device=0, stream=stream.cuda_stream)
 dev = torch.device("cuda", 0)
 ix = _native.Index(rt, dim, metric="L2")
 ix.fill_synthetic(rows, seed=0)
+import os
+if os.environ.get("SC_Q_MODE"):
+    ix.set_search_mode(os.environ["SC_Q_MODE"])  # e.g. "batched": the coarse stages for every batch size
 q = torch.empty((1024, dim), dtype=torch.float32, device=dev)
 rt.synth_fill_dev(q.data_ptr(), 1024, dim, dim, seed=1)
 od = torch.empty((1024, k), dtype=torch.float32, device=dev)

@@ -655,12 +655,21 @@ static int64_t phase0_rows() {
     return v;
 }
 
+static int coarse_pin(const sc_index* ix);
+static int i8_min_queries() {
+    static const int v = [] { const char* e = getenv("SC_I8_MINQ"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
     if (k > sc_batched_kprime() / 2 || ix->n < 1) return false;
     if (ix->search_mode == 2) return true;
     static const int64_t min_rows = [] { const char* e = getenv("SC_BATCHED_MINROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();  // A/B
-    return Q > 16 && ix->n >= min_rows;
+    if (Q > 16) return ix->n >= min_rows;
+    // 16 queries and fewer: the exact scan reads the f32 rows once (10M x 768: 4.8 ms); where the int8 stage may run, its narrow
+    // streaming kernel reads a quarter of the bytes and the certificate still makes the result exact: 1.7 ms for one query, 1.9 for
+    // 16 (scripts/q_sweep.py, profiles/r3z_q_small.log).  SC_I8_MINQ > 1 restores the exact scan below that many queries (A/B).
+    return ix->n >= ((int64_t)1 << 20) && !ix->i8_off && coarse_pin(ix) != 16 && Q >= i8_min_queries();
 }
 
 // The int8 stage is tried first (twice the MFMA rate, half the shadow bytes); what it cannot certify goes to the bf16 stage, and
@@ -945,7 +954,7 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     // 3.8 ms of the bf16 stage's 128-query tiles (profiles/r2p_bench.json.log sweep vs r1v)
     // (round 3: the persistent int8 kernel answers a 32-query batch in 3.1 ms where the bf16 stage's 128-query tiles take 3.9: the
     // int8 stage now starts at 17 queries; SC_I8_MINQ restores any other limit for A/B runs)
-    static const int i8_minq = [] { const char* e = getenv("SC_I8_MINQ"); return e ? atoi(e) : 17; }();
+    const int i8_minq = i8_min_queries();  // (round 3, later: from one query on -- batched_applicable)
     const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= ((int64_t)1 << 20) && Q >= i8_minq) || ix->search_mode == 2));
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
