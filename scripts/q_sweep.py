@@ -7,7 +7,8 @@ import torch
 
 from semcode_amd import _native
 
-rows, dim, k = 10_000_000, 768, 10
+import os
+rows, dim, k = int(os.environ.get('SC_Q_ROWS', 10_000_000)), 768, 10
 stream = torch.cuda.Stream()
 rt = _native.Runtime(device=0, stream=stream.cuda_stream)
 dev = torch.device("cuda", 0)

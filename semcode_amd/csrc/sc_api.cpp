@@ -656,6 +656,10 @@ static int64_t phase0_rows() {
 }
 
 static int coarse_pin(const sc_index* ix);
+static int64_t i8_min_rows() {  // corpora below this never build an int8 shadow (SC_I8_MINROWS: A/B)
+    static const int64_t v = [] { const char* e = getenv("SC_I8_MINROWS"); return e ? (int64_t)atoll(e) : ((int64_t)1 << 20); }();
+    return v;
+}
 static int i8_min_queries() {
     static const int v = [] { const char* e = getenv("SC_I8_MINQ"); return e ? atoi(e) : 1; }();
     return v;
@@ -669,7 +673,7 @@ static bool batched_applicable(const sc_index* ix, int Q, int k) {
     // 16 queries and fewer: the exact scan reads the f32 rows once (10M x 768: 4.8 ms); where the int8 stage may run, its narrow
     // streaming kernel reads a quarter of the bytes and the certificate still makes the result exact: 1.7 ms for one query, 1.9 for
     // 16 (scripts/q_sweep.py, profiles/r3z_q_small.log).  SC_I8_MINQ > 1 restores the exact scan below that many queries (A/B).
-    return ix->n >= ((int64_t)1 << 20) && !ix->i8_off && coarse_pin(ix) != 16 && Q >= i8_min_queries();
+    return ix->n >= i8_min_rows() && !ix->i8_off && coarse_pin(ix) != 16 && Q >= i8_min_queries();
 }
 
 // The int8 stage is tried first (twice the MFMA rate, half the shadow bytes); what it cannot certify goes to the bf16 stage, and
@@ -700,7 +704,7 @@ static sc_status search_collect_locked(sc_index* ix, const float* fq, int R, int
     sc_runtime* rt = ix->rt;
     hipStream_t s = rt->stream;
     const int metric = (int)ix->metric, ld = ix->ld, ld8 = ld8_of(ix);
-    const int Qpad = (i8 || R > 128) ? (R + 255) / 256 * 256 : 128;
+    const int Qpad = (i8 || R > 64) ? (R + 255) / 256 * 256 : 128;
     static_assert(BATCH_CAP == 4096, "the refine kernels' candidate stride (sc_ivf_widen_cap) is the survivor cap");
     if (sc_ivf_widen_cap() != BATCH_CAP) return sc_fail(SC_ERR_STATE, "collect pass: candidate stride mismatch");
     sc_status st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)R * ld * 4);
@@ -754,7 +758,9 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     hipStream_t s = rt->stream;
     const int metric = (int)ix->metric, ld = ix->ld, KP = i8 ? sc_batched_kprime8() : sc_batched_kprime();
     const int ld8 = ld8_of(ix);
-    const int Qpad = (i8 || Q > 128) ? (Q + 255) / 256 * 256 : 128;  // 256-wide query tiles for large batches (always for the int8 stage)
+    // 256-wide query tiles for batches above 64 queries (always for the int8 stage); 65 .. 128 queries used to take the 128-query tiles:
+    // 1M x 768, 65 queries 2.02 ms there against 0.86 ms for 256 queries on the 256-wide tiles (profiles/r3z_q_rows.log)
+    const int Qpad = (i8 || Q > 64) ? (Q + 255) / 256 * 256 : 128;
     // the wide candidate set (scan_batched.hip): on corpora whose certificate fails at kp candidates the int8 stage keeps every key
     // within its exact-score cut -- needs the cuts (tightening: 2 k <= 128, a corpus beyond 2^17 rows) and 64 KiB of keys per query
     static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
@@ -955,7 +961,9 @@ static sc_status search_batched_locked(sc_index* ix, const float* q_dev, int32_t
     // (round 3: the persistent int8 kernel answers a 32-query batch in 3.1 ms where the bf16 stage's 128-query tiles take 3.9: the
     // int8 stage now starts at 17 queries; SC_I8_MINQ restores any other limit for A/B runs)
     const int i8_minq = i8_min_queries();  // (round 3, later: from one query on -- batched_applicable)
-    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= ((int64_t)1 << 20) && Q >= i8_minq) || ix->search_mode == 2));
+    const bool i8 = env == 8 || (env == 0 && !ix->i8_off && ((ix->n >= i8_min_rows() && Q >= i8_minq) || (Q > 16 && Q <= 64 && ix->n >= 65536) || ix->search_mode == 2));
+    // (17 .. 64 queries from 65 536 rows on: that batch size is the narrow streaming kernel's -- 1M x 768, 64 queries: 0.71 ms against
+    // 2.01 through the bf16 stage's 128-query tiles; 300k rows: 0.51 against 1.74 -- profiles/r3z_q_rows.log)
     ix->last_coarse_bits = i8 ? 8 : 16;
     ix->last_uncert_i8 = 0;
     ix->last_uncertified = 0;
