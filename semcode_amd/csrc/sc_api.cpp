@@ -666,7 +666,15 @@ static int i8_min_queries() {
 }
 static bool batched_applicable(const sc_index* ix, int Q, int k) {
     if (ix->search_mode == 1) return false;
-    if (k > sc_batched_kprime() / 2 || ix->n < 1) return false;
+    if (ix->n < 1) return false;
+    // top_k beyond 64: only the int8 stage has the candidates for it (512: k <= 256); without it the exact scan answers -- one pass
+    // per 16 queries, the cliff this removes where the int8 stage may run (10M x 768, 256 queries, top-100: see profiles/r3z_k100.log)
+    if (k > sc_batched_kprime() / 2) {
+        // (up to 128: beyond, the keys within the cut outgrow the wide set's 4 096 -- 256 queries, top-256 overflowed for most of them)
+        const bool i8_ok = k <= sc_batched_kprime8() / 4 && !ix->i8_off && coarse_pin(ix) != 16 && (ix->n >= i8_min_rows() || ix->search_mode == 2);
+        if (!i8_ok) return false;
+        return ix->search_mode == 2 || Q >= i8_min_queries();
+    }
     if (ix->search_mode == 2) return true;
     static const int64_t min_rows = [] { const char* e = getenv("SC_BATCHED_MINROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();  // A/B
     if (Q > 16) return ix->n >= min_rows;
@@ -764,9 +772,14 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
     // the wide candidate set (scan_batched.hip): on corpora whose certificate fails at kp candidates the int8 stage keeps every key
     // within its exact-score cut -- needs the cuts (tightening: 2 k <= 128, a corpus beyond 2^17 rows) and 64 KiB of keys per query
     static const bool tighten_env = [] { const char* e = getenv("SC_TIGHTEN"); return !(e && e[0] == '0'); }();  // A/B
-    const bool tighten = tighten_env && g_tighten && 2 * k <= 128;
+    // (the cut needs the k-th exact score among re-scored candidates: the 128 best for k <= 64, all 512 of the int8 stage beyond)
+    const bool tighten = tighten_env && g_tighten && (2 * k <= 128 || (i8 && 2 * k <= KP));
+    const int TK = 2 * k <= 128 ? 128 : KP;
     const int WB = BATCH_CAP;  // capacity of the wide set
-    const bool wide = i8 && tighten && (ix->wide_i8 || g_wide_force) && depth == 0 && Q <= 16384 && ix->n > ((int64_t)1 << 18);
+    // (top_k beyond 64 goes straight to the wide form: the 512-candidate certificate is hopeless there -- 256 queries, top-100 over 10M x 768:
+    // 5.9 ms, against 211 ms through the exact scan, profiles/r3z_k100.log)
+    const bool big_k = k > sc_batched_kprime() / 2;
+    const bool wide = i8 && tighten && (ix->wide_i8 || g_wide_force || big_k) && depth == 0 && Q <= 16384 && ix->n > ((int64_t)1 << 18);
     const int KB = wide ? WB : KP;  // row stride of `best`
     sc_status st = i8 ? ensure_shadow8(ix) : ensure_shadow(ix);
     if (st) return st;
@@ -782,7 +795,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
                  o_tf = carve((size_t)Qpad * 4), o_cnt = carve((size_t)Q * 4), o_ovf = carve((size_t)Q * 4), o_flag = carve((size_t)Q * 4),
                  o_best = carve((size_t)Q * KB * 8), o_ek = carve(i8 ? (size_t)Q * KB * 8 : 16), o_surv = carve((size_t)Q * BATCH_CAP * 8),
                  o_nbest = carve((size_t)Q * 4), o_wcand = carve((size_t)Q * KB * 8), o_wnc = carve((size_t)Q * 4),
-                 o_b128 = carve((size_t)Q * 128 * 8), o_e128 = carve((size_t)Q * 128 * 8), o_cut = carve((size_t)Qpad * 4), o_cnt2 = carve((size_t)Q * 4),
+                 o_b128 = carve((size_t)Q * 512 * 8), o_e128 = carve((size_t)Q * 512 * 8), o_cut = carve((size_t)Qpad * 4), o_cnt2 = carve((size_t)Q * 4),
                  o_thrT = carve((size_t)Qpad * 4), o_tfT = carve((size_t)Qpad * 4);
     // per-wave hit lists of the narrow int8 kernel (batches of <= 64 queries): 2048 lists x 1024 entries of 16 B
     const size_t hit_bytes = (i8 && Q <= 64) ? (size_t)2048 * (4 + 1024 * 16) + 256 : 0;
@@ -822,15 +835,15 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
             unsigned* cnt2 = (unsigned*)(b + o_cnt2);
             sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
             const uint64_t* from = best;
-            if (KP > 128) {  // the 128 best of the kp candidates (a selection over `best` as if it were a survivor list)
+            if (wide || KP > TK) {  // the TK best of the candidates (a selection over `best` as if it were a survivor list)
                 if (wide) SC_HIP(hipMemcpyAsync(cnt2, nbest, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
                 else sc_launch_fill_u32(cnt2, (unsigned)KP, Q, s);
-                SC_HIP(hipMemsetAsync(b128, 0xFF, (size_t)Q * 128 * 8, s));
-                sc_launch_scan_select(metric, best, cnt2, KB, b128, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), (int*)(b + o_wnc), Q, 128, s);
+                SC_HIP(hipMemsetAsync(b128, 0xFF, (size_t)Q * TK * 8, s));
+                sc_launch_scan_select(metric, best, cnt2, KB, b128, ix->qnorm, (float*)(b + o_thrT), (float*)(b + o_tfT), (int*)(b + o_wnc), Q, TK, s);
                 from = b128;
             }
-            sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, from, nullptr, 128, ix->perm, e128, Q, s);
-            sc_launch_scan_tighten(metric, e128, 128, k, ix->qnorm, qres, i8 ? ix->xnorm_max8 : ix->xnorm_max, ld, thr, tf, thr_cut, Q, s);
+            sc_launch_scan_rerank_keys(metric, ix->X, ix->xnorm, ld, ix->qpad, ix->qnorm, from, nullptr, TK, ix->perm, e128, Q, s);
+            sc_launch_scan_tighten(metric, e128, TK, k, ix->qnorm, qres, i8 ? ix->xnorm_max8 : ix->xnorm_max, ld, thr, tf, thr_cut, Q, s);
             sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
             cut_used = true;
         }
@@ -882,7 +895,7 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         // most of a real batch uncertified: this corpus does not quantise well enough (tight clusters, outlier dimensions) --
         // later searches start at the bf16 stage until the rows are replaced wholesale
         // (first resort: the wide candidate set -- the next batch keeps every key within the exact-score cut; if that fails too, bf16)
-        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8 && !ix->i8_sticky) {
+        if (depth == 0 && Q >= 32 && R * 4 > Q && coarse_pin(ix) != 8 && !ix->i8_sticky && !big_k) {  // (a large top_k says nothing about the corpus)
             const bool wide_possible = tighten && Q <= 16384 && ix->n > ((int64_t)1 << 18);
             if (!wide && wide_possible && !ix->wide_i8) ix->wide_i8 = true;
             else ix->i8_off = true;
@@ -919,7 +932,8 @@ static sc_status search_batched_stage_locked(sc_index* ix, const float* q_dev, i
         R = (int)redo.size();
     }
     if (i8) ix->last_uncert_i8 = R;
-    const bool to_bf16 = i8 && coarse_pin(ix) != 8 && R > 16;  // a handful of queries is one pass of the exact scan: not worth a bf16 shadow
+    // (a handful of queries is one pass of the exact scan: not worth a bf16 shadow; top_k beyond 64 is beyond the bf16 stage's 128 candidates)
+    const bool to_bf16 = i8 && coarse_pin(ix) != 8 && R > 16 && k <= sc_batched_kprime() / 2;
     if (!to_bf16) {  // what is left goes to the exact scan
         ix->last_uncertified = R;
         ix->uncert_frac = (double)R / (double)Q_top;

@@ -988,16 +988,17 @@ template <int METRIC>
 __global__ __launch_bounds__(128) void scan_tighten_kernel(const uint64_t* __restrict__ ekeys, int kp, int k, const float* __restrict__ qnorm,
                                                             const float* __restrict__ qres, const unsigned* __restrict__ bits, int ld,
                                                             float* __restrict__ thr, float* __restrict__ thr_fast, float* __restrict__ thr_cut) {
-    __shared__ uint64_t keys[128];
+    __shared__ uint64_t keys[512];  // kp = 128 (k <= 64) or 512 (k <= 256: every candidate of the int8 stage)
     __shared__ float s_v;
     const int q = blockIdx.x, tid = threadIdx.x;
-    keys[tid] = tid < kp ? ekeys[(size_t)q * kp + tid] : SC_KEY_MAX;
+    for (int i = tid; i < kp; i += 128) keys[i] = ekeys[(size_t)q * kp + i];
     if (tid == 0) s_v = __builtin_inff();
     __syncthreads();
-    const uint64_t key = keys[tid];
-    if (key != SC_KEY_MAX) {
+    for (int i = tid; i < kp; i += 128) {
+        const uint64_t key = keys[i];
+        if (key == SC_KEY_MAX) continue;
         int rank = 0;
-        for (int j = 0; j < 128; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
+        for (int j = 0; j < kp; ++j) rank += keys[j] < key ? 1 : 0;  // exact keys are unique (row id in the low word)
         if (rank == k - 1) {
             const float sc = sc_key_score(METRIC, key);
             s_v = (METRIC == SC_METRIC_L2) ? sc : -sc;

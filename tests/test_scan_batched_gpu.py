@@ -286,3 +286,25 @@ def test_wide_candidate_set_answers_clustered_batches_in_one_pass(rt, metric):
     finally:
         _native.diag_set_option("wide_candidates", 0)
         ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_top_k_beyond_64_takes_the_wide_form_of_the_int8_stage(rt, metric):
+    """top_k 65 .. 128 used to fall to the exact scan (one pass per 16 queries); the int8 stage's wide form (512 candidates re-scored for
+    the cut, every key within it kept) answers it with the same bits.  top_k beyond 128 still takes the exact scan."""
+    n, dim = 300_000, 64
+    ix = _native.Index(rt, dim, metric=metric)
+    ix.fill_synthetic(n, seed=11)
+    Q = orc.synth(40, dim, seed=12)
+    ix.set_search_mode("exact")
+    d0, r0 = ix.search(Q, k=100)
+    ix.set_search_mode("batched")
+    d1, r1 = ix.search(Q, k=100)
+    st = ix.last_search_stats()
+    assert st["path"] == "batched" and st["coarse_bits"] == 8 and st["wide"], st
+    assert np.array_equal(r0, r1) and np.array_equal(bits(d0), bits(d1)), st
+    d2, r2 = ix.search(Q, k=200)
+    assert ix.last_search_stats()["path"] == "exact"
+    d3, r3 = ix.search(Q[:5], k=10)  # the large top_k left no switch behind
+    assert ix.last_search_stats()["path"] == "batched" and not ix.last_search_stats()["wide"]
+    ix.close()
