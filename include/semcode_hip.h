@@ -199,7 +199,9 @@ sc_status sc_diag_encoder_read(sc_encoder* enc, int32_t which, void* out, size_t
  * "coarse_persistent": 0 = one workgroup per tile instead; "gemm_pp": main loop of the 256-tile GEMMs (-1 default, 0 = one barrier
  * per K-tile, 2..5 = ping-pong with that many half-tiles in flight); "ivf_refresh_nomem": 1 = the re-layout of a trained IVF index
  * after upserts fails as if the device were full (the search must then answer exhaustively instead of failing); "tighten": 0 = the batched scan's thresholds stay the kp-th best coarse keys
- * (no exact re-score of the 128 best before the large phases); "wide_candidates": 1 = the int8 stage keeps every key within its cut
+ * (no exact re-score of the 128 best before the large phases); "ivf_tail_rows": how many rows appended to a trained IVF_FLAT index may
+ * stay behind its lists as a tail that probes scan exactly (-1 = default 65536; 0 = fold appended rows into the lists before every search);
+ * "wide_candidates": 1 = the int8 stage keeps every key within its cut
  * (the form it otherwise switches to on corpora whose certificate fails) wherever it can; "collect_pass": 0 = queries a
  * coarse stage cannot certify go straight to the next stage (no collect pass); "ivf_coarse_nomem": 1 = the IVF coarse stage
  * cannot allocate its centred shadow (the search must then probe exactly instead of failing); "ivf_refine_cap":
@@ -310,6 +312,10 @@ sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, int32_t* res
 /* 1 if the last batched search ran the int8 stage in its wide form: every key within the exact-score cut kept between the phases
  * (up to 4 096 per query) instead of the 512 best -- what the stage switches to on corpora whose certificate fails (clusters). */
 sc_status sc_index_last_wide(sc_index* ix, int32_t* wide);
+/* Rows the last search scanned exactly BEHIND the lists of a trained IVF_FLAT index: rows appended since the lists were laid out stay
+ * there (up to 65 536) instead of forcing a re-layout before the next search -- Milvus' brute-force search of its growing segment;
+ * 0 = the lists covered every stored row. */
+sc_status sc_index_last_tail_rows(sc_index* ix, int64_t* rows);
 
 /* After an IVF probe search: rows of the DISTINCT lists the batch probed (`unique_rows`: the algorithmic bytes of SURVEY.md 8d
  * config 5 = unique_rows * ld * 4), rows the scan kernel streamed (`streamed_rows`: list-major probing streams a list once per

@@ -104,6 +104,7 @@ SIGNATURES = {
     "sc_index_last_coarse_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_collect_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sc_index_last_wide": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "sc_index_last_tail_rows": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
     "sc_index_last_probe_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "sc_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_size_t]),
     "sc_comm_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -377,6 +378,10 @@ class Index:
         _check(lib().sc_index_last_search_stats(self.handle, C.byref(path), C.byref(unc)))
         _check(lib().sc_index_last_coarse_stats(self.handle, C.byref(bits), C.byref(handed)))
         out = {"path": {0: "none", 1: "exact", 2: "batched", 3: "ivf", 4: "ivf_listmajor", 5: "ivf_coarse"}[path.value], "uncertified": unc.value}
+        if path.value in (3, 4, 5):
+            tail = C.c_int64()
+            _check(lib().sc_index_last_tail_rows(self.handle, C.byref(tail)))
+            out["tail_rows"] = int(tail.value)
         if path.value == 2:
             tried, resolved = C.c_int32(), C.c_int32()
             _check(lib().sc_index_last_collect_stats(self.handle, C.byref(tried), C.byref(resolved)))

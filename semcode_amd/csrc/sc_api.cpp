@@ -234,6 +234,7 @@ extern "C" sc_status sc_index_destroy(sc_index* ix) {
     hipFree(ix->bscratch);
     hipFree(ix->fb);
     hipFree(ix->fb2);
+    hipFree(ix->tailbuf);
     hipFree(ix->perm);
     hipFree(ix->list_off);
     hipFree(ix->ivf_scratch);
@@ -524,6 +525,7 @@ extern "C" sc_status sc_index_release_scratch(sc_index* ix) {
     hipFree(ix->stage); ix->stage = nullptr; ix->stage_cap = 0;
     hipFree(ix->fb); ix->fb = nullptr; ix->fb_cap = 0;
     hipFree(ix->fb2); ix->fb2 = nullptr; ix->fb2_cap = 0;
+    hipFree(ix->tailbuf); ix->tailbuf = nullptr; ix->tailbuf_cap = 0;
     hipFree(ix->ivf_scratch); ix->ivf_scratch = nullptr; ix->ivf_scratch_cap = 0;
     return SC_OK;
 }
@@ -563,6 +565,34 @@ static sc_status search_exact_locked(sc_index* ix, const float* q_dev, int32_t Q
     return SC_OK;
 }
 
+
+// the exact scan over stored rows [first, first + nrows) only: positions there equal row ids (the tail behind the lists of a trained
+// IVF index)
+static sc_status search_exact_range_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int64_t first, int64_t nrows, float* out_dist,
+                                           int64_t* out_rows) {
+    sc_runtime* rt = ix->rt;
+    hipStream_t s = rt->stream;
+    ScanPlan plan;
+    if (!sc_scan_exact_plan(ix->ld, Q, k, rt->cus, &plan, 0, 0, nrows))
+        return sc_fail(SC_ERR_UNSUPPORTED, "search: k=%d (1..1024) / dim=%d not supported by the exact scan", k, ix->dim);
+    sc_status st = sc_grow(ix, (void**)&ix->qpad, &ix->qpad_cap, (size_t)Q * ix->ld * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->qnorm, &ix->qnorm_cap, (size_t)Q * 4);
+    if (st) return st;
+    st = sc_grow(ix, (void**)&ix->partial, &ix->partial_cap, std::max<size_t>(plan.partial_bytes, 16));
+    if (st) return st;
+    sc_launch_ingest_rows(q_dev, nullptr, 0, Q, ix->dim, ix->qpad, ix->ld, ix->qnorm, s);
+    hipEvent_t e0, e1;
+    sc_prof_begin(rt, SC_PROF_SCAN, &e0, &e1);
+    sc_launch_scan_exact((int)ix->metric, ix->X + (size_t)first * ix->ld, ix->xnorm + first, nrows, ix->ld, ix->qpad, ix->qnorm, Q, k, plan, ix->partial, nullptr, nullptr,
+                         nullptr, 0, s);
+    sc_prof_end(rt, SC_PROF_SCAN, e0, e1);
+    sc_prof_begin(rt, SC_PROF_MERGE, &e0, &e1);
+    sc_launch_topk_merge((int)ix->metric, ix->partial, plan.groups, plan.lists, plan.qt, Q, k, ix->row_base + first, out_dist, out_rows, s);
+    sc_prof_end(rt, SC_PROF_MERGE, e0, e1);
+    SC_HIP(hipGetLastError());
+    return SC_OK;
+}
 
 // ---- batched path (scan_batched.hip): bf16 shadow + coarse GEMM phases + exact re-rank + certified fallback
 
@@ -1015,11 +1045,48 @@ sc_status sc_search_flat_locked(sc_index* ix, const float* q_dev, int32_t Q, int
     return search_exact_locked(ix, q_dev, Q, k, 0, out_dist, out_rows);
 }
 
+static int64_t g_ivf_tail_rows = 65536;  // sc_diag_set_option("ivf_tail_rows", n): appended rows a trained index leaves behind its lists (0: fold them in at once)
+void sc_set_ivf_tail_rows(int v) { g_ivf_tail_rows = v < 0 ? 65536 : v; }
+
+static sc_status probe_dispatch_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows);
+
 static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist,
                                    int64_t* out_rows) {
     ix->last_probed_lists = 0;
     ix->last_unique_rows = ix->last_streamed_rows = 0;
     ix->last_groups = 0;
+    ix->last_tail_rows = 0;
+    // Rows APPENDED to a trained index since its lists were laid out.  Folding them in means re-ordering the corpus (a second copy
+    // of it, the shadows that mirror the layout): 1.9 - 4.1 s per search at 10M x 768 when searches and upserts alternate
+    // (scripts/upsert_search_interleave.py).  Milvus answers from its growing segment by brute force; the same here: up to 65 536
+    // appended rows stay behind the lists as a tail, a probe answers from the lists AND from an exact scan of the tail (positions
+    // there are row ids), merged; beyond that, or when listed rows were overwritten (their list may have changed), or for an
+    // exhaustive search, the lists are refreshed as before.  A tail row is always seen -- the probed lists plus the whole tail --
+    // so recall can only be higher than after the refresh.
+    {
+        const int64_t tail = (ix->kind == SC_INDEX_IVF_FLAT && ix->trained && ix->perm) ? ix->n - ix->ivf_rows : 0;
+        if (tail > 0 && tail <= g_ivf_tail_rows && ix->dirty_rows.empty() && ix->search_mode != 1 && ix->search_mode != 2 && nprobe >= 1 && nprobe < ix->nlist_trained &&
+            (sc_ivf_coarse_applicable(ix, Q, k, nprobe) || sc_ivf_applicable(ix, Q, nprobe) ||
+             sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))) {
+            const size_t db = ((size_t)Q * k * 4 + 255) & ~(size_t)255, rb = ((size_t)Q * k * 8 + 255) & ~(size_t)255;
+            sc_status st = sc_grow(ix, &ix->tailbuf, &ix->tailbuf_cap, 2 * (db + rb));
+            if (st) return st;
+            char* tb = (char*)ix->tailbuf;
+            float *d1 = (float*)tb, *d2 = (float*)(tb + db);
+            int64_t *r1 = (int64_t*)(tb + 2 * db), *r2 = (int64_t*)(tb + 2 * db + rb);
+            st = probe_dispatch_locked(ix, q_dev, Q, k, nprobe, d1, r1);
+            if (st) return st;
+            const int path = ix->last_path, unc = ix->last_uncertified;
+            st = search_exact_range_locked(ix, q_dev, Q, k, ix->ivf_rows, tail, d2, r2);
+            if (st) return st;
+            sc_launch_topk_merge2((int)ix->metric, d1, r1, d2, r2, k, out_dist, out_rows, Q, ix->rt->stream);
+            SC_HIP(hipGetLastError());
+            ix->last_path = path;
+            ix->last_uncertified = unc;
+            ix->last_tail_rows = tail;
+            return SC_OK;
+        }
+    }
     {   // rows upserted since the IVF lists were built join their lists first (no k-means): the reported ids of a
         // list-major corpus go through ix->perm, which must cover every stored row
         sc_status rst = sc_ivf_refresh_locked(ix);
@@ -1033,6 +1100,11 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
         }
         if (rst) return rst;
     }
+    return probe_dispatch_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+}
+
+// which path answers (the lists cover every stored row, or the caller takes care of the tail)
+static sc_status probe_dispatch_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows) {
     if (!sc_ivf_coarse_applicable(ix, Q, k, nprobe) && sc_ivf_applicable(ix, Q, nprobe)) return sc_ivf_search_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
     if (sc_ivf_coarse_applicable(ix, Q, k, nprobe)) {
         // per-query scratch of the coarse stage is ~200 KB (two survivor lists of 8 192 keys, the refine sets): very large batches go
@@ -1068,6 +1140,10 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
 exact_probe:
     if (sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))
         return sc_ivf_search_listmajor_locked(ix, q_dev, Q, k, nprobe, out_dist, out_rows);
+    if (ix->perm && ix->perm_rows < ix->n && ix->n > ix->ivf_rows) {  // (a tail behind the lists: the exhaustive paths need every position mapped)
+        const sc_status cst = sc_ivf_cover_tail_locked(ix);
+        if (cst) return cst;
+    }
     return sc_search_flat_locked(ix, q_dev, Q, k, out_dist, out_rows);
 }
 sc_status sc_search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, int32_t k, int32_t nprobe, float* out_dist, int64_t* out_rows) {
@@ -1113,6 +1189,13 @@ extern "C" sc_status sc_index_last_collect_stats(sc_index* ix, int32_t* tried, i
     std::lock_guard<std::mutex> g(ix->mu);
     if (tried) *tried = ix->last_collect_tried;
     if (resolved) *resolved = ix->last_collect_resolved;
+    return SC_OK;
+}
+
+extern "C" sc_status sc_index_last_tail_rows(sc_index* ix, int64_t* rows) {
+    if (!ix) return sc_fail(SC_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (rows) *rows = ix->last_tail_rows;
     return SC_OK;
 }
 

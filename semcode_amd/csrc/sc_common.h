@@ -141,6 +141,8 @@ void sc_launch_topk_merge(int metric, const uint64_t* partial, int groups, int l
 // lists_per_query sorted k-lists per query, list j of query q = partial[src[q * lists_per_query + j] * k ...] (src < 0: none);
 // needs 2 * lists_per_query * k * 8 <= 128 KiB (sc_topk_gather_merge_supported)
 bool sc_topk_gather_merge_supported(int lists_per_query, int k);
+void sc_launch_topk_merge2(int metric, const float* d1, const int64_t* r1, const float* d2, const int64_t* r2, int k, float* out_dist, int64_t* out_rows, int Q,
+                           hipStream_t s);
 void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int32_t* src, int lists_per_query, int Q, int k,
                                  int64_t row_base, float* out_dist, int64_t* out_rows, hipStream_t s);
 

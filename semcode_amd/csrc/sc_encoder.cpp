@@ -677,6 +677,7 @@ void sc_ivf_set_coarse_nomem(int v);
 void sc_set_collect_pass(int v);
 void sc_set_tighten(int v);
 void sc_set_wide_force(int v);
+void sc_set_ivf_tail_rows(int v);
 extern "C" sc_status sc_diag_set_option(const char* name, int32_t value) {
     if (!name) return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: NULL name");
     if (!strcmp(name, "coarse_workgroups")) sc_scan_set_coarse_workgroups(value);
@@ -688,6 +689,7 @@ extern "C" sc_status sc_diag_set_option(const char* name, int32_t value) {
     else if (!strcmp(name, "collect_pass")) sc_set_collect_pass(value);
     else if (!strcmp(name, "tighten")) sc_set_tighten(value);
     else if (!strcmp(name, "wide_candidates")) sc_set_wide_force(value);
+    else if (!strcmp(name, "ivf_tail_rows")) sc_set_ivf_tail_rows(value);
     else return sc_fail(SC_ERR_INVALID, "sc_diag_set_option: unknown option '%s'", name);
     return SC_OK;
 }

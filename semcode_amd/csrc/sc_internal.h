@@ -81,7 +81,9 @@ struct sc_index {
     int last_collect_tried = 0, last_collect_resolved = 0;  // queries of the last batched search that went through a collect pass / that it answered
     void* bscratch = nullptr; size_t bscratch_cap = 0;
     void* fb = nullptr;      size_t fb_cap = 0;   // fallback staging (queries + results) of the first stage's uncertified queries
-    void* fb2 = nullptr;     size_t fb2_cap = 0;  // the same for the second stage (int8 -> bf16 -> exact)
+    void* fb2 = nullptr;     size_t fb2_cap = 0;
+    void* tailbuf = nullptr; size_t tailbuf_cap = 0;  // two [Q][k] result sets of a search that answers from the lists and from the tail (sc_api.cpp)
+    int64_t last_tail_rows = 0;                   // rows the last search scanned behind the lists (0: none)  // the same for the second stage (int8 -> bf16 -> exact)
     // IVF_FLAT (after sc_index_train): X / xnorm are stored list-major
     sc_index* quant = nullptr;                    // flat index over the nlist centroids (coarse quantizer)
     uint32_t* perm = nullptr;                     // device [ivf_rows]: stored position -> row id (insertion order)

@@ -133,3 +133,41 @@ void sc_launch_topk_gather_merge(int metric, const uint64_t* partial, const int3
     hipLaunchKernelGGL(topk_tree_merge_kernel, dim3((unsigned)Q), dim3(MERGE_THREADS), tree_lds, s, metric, partial, lists_per_query, 1, Q, k,
                        row_base, out_dist, out_rows, src, 0, (uint64_t*)nullptr);
 }
+
+// Two result sets of one batch, each [Q][k] best first (unfilled: row -1), over DISJOINT rows -> the best k of their union, same order
+// rule (score, then row id).  One thread per query: the lists are short.  Used where a trained IVF index answers from its lists and
+// from the tail of rows appended since the lists were laid out (sc_api.cpp).
+__global__ __launch_bounds__(64) void topk_merge2_kernel(int metric, const float* __restrict__ d1, const int64_t* __restrict__ r1, const float* __restrict__ d2,
+                                                          const int64_t* __restrict__ r2, int k, float* __restrict__ out_dist, int64_t* __restrict__ out_rows, int Q) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Q) return;
+    const size_t o = (size_t)q * k;
+    int a = 0, b = 0;
+    for (int j = 0; j < k; ++j) {
+        const bool ha = a < k && r1[o + a] >= 0, hb = b < k && r2[o + b] >= 0;
+        bool take_a;
+        if (ha && hb) {
+            const float x = d1[o + a], y = d2[o + b];
+            const bool better = metric == SC_METRIC_L2 ? x < y : x > y;
+            take_a = better || (x == y && r1[o + a] < r2[o + b]);
+        } else {
+            take_a = ha;
+        }
+        if (!ha && !hb) {
+            out_dist[o + j] = (metric == SC_METRIC_L2) ? __builtin_inff() : -__builtin_inff();
+            out_rows[o + j] = -1;
+        } else if (take_a) {
+            out_dist[o + j] = d1[o + a];
+            out_rows[o + j] = r1[o + a];
+            ++a;
+        } else {
+            out_dist[o + j] = d2[o + b];
+            out_rows[o + j] = r2[o + b];
+            ++b;
+        }
+    }
+}
+void sc_launch_topk_merge2(int metric, const float* d1, const int64_t* r1, const float* d2, const int64_t* r2, int k, float* out_dist, int64_t* out_rows, int Q,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(topk_merge2_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, s, metric, d1, r1, d2, r2, k, out_dist, out_rows, Q);
+}

@@ -432,6 +432,60 @@ def test_coarse_stage_follows_a_retrain_and_takes_huge_batches_in_chunks(rt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_rows_appended_to_a_trained_index_are_searched_as_a_tail_without_a_relayout(rt, metric):
+    """Appends to a trained index do not force a re-layout before the next probe (seconds at 10M rows): up to 65 536 appended rows stay
+    behind the lists and every probe also scans them exactly.  Result = best k of (probe of the lists) and (exact search of the tail),
+    whichever probe path answers; ivf_info() (or a tail beyond its limit) folds them into the lists as before."""
+    X, centers = clustered(120_000, 64, 40, seed=91)
+    rng = np.random.default_rng(92)
+    Q = (centers[rng.integers(0, 40, size=90)] + 0.3 * rng.standard_normal((90, 64))).astype(np.float32)
+    T = (centers[rng.integers(0, 40, size=700)] + 0.3 * rng.standard_normal((700, 64))).astype(np.float32)
+    T[:40] = Q[:40] + np.float32(1e-3)  # appended rows that must show up at the top
+    modes = (("ivf", 3), ("ivf_listmajor", 90), ("ivf_coarse", 90), ("auto", 90), ("auto", 1))
+    ix = _native.Index(rt, 64, metric=metric, kind="IVF_FLAT", nlist=32)
+    tailix = _native.Index(rt, 64, metric=metric, row_base=len(X))
+    try:
+        ix.add(X)
+        ix.train(niter=4)
+        lists_only = {}
+        for mode, nq in modes:  # the lists alone, before anything is appended
+            ix.set_search_mode(mode)
+            lists_only[(mode, nq)] = ix.search(Q[:nq], k=10, nprobe=5)
+            assert ix.last_search_stats().get("tail_rows", 0) == 0
+        ix.add(T)
+        tailix.add(T)
+        tailix.set_search_mode("exact")
+        dt, rt_ = tailix.search(Q, k=10)
+        for mode, nq in modes:
+            ix.set_search_mode(mode)
+            d, r = ix.search(Q[:nq], k=10, nprobe=5)
+            st = ix.last_search_stats()
+            assert st["path"].startswith("ivf") and st["tail_rows"] == 700, (mode, st)
+            dp, rp = lists_only[(mode, nq)]
+            for i in range(nq):  # best 10 of the two disjoint sets, order = (score, row id)
+                cd = np.concatenate([dp[i], dt[i]])
+                cr = np.concatenate([rp[i], rt_[i]])
+                keep = cr >= 0
+                cd, cr = cd[keep], cr[keep]
+                order = np.lexsort((cr, cd if metric == "L2" else -cd))[:10]
+                assert np.array_equal(r[i], cr[order]) and np.array_equal(bits(d[i]), bits(cd[order])), (mode, i)
+            if nq >= 40 and metric == "L2":
+                assert (r[:40, 0] == len(X) + np.arange(40)).all()  # the planted rows lead their queries
+        info = ix.ivf_info()  # folds the tail into the lists
+        assert int(info["list_sizes"].sum()) == len(X) + 700
+        ix.set_search_mode("auto")
+        ix.search(Q, k=10, nprobe=5)
+        assert ix.last_search_stats()["tail_rows"] == 0
+        _native.diag_set_option("ivf_tail_rows", 0)  # no tail allowed: an append is folded in by the very next search
+        ix.add(T[:10])
+        ix.search(Q, k=10, nprobe=5)
+        assert ix.last_search_stats()["tail_rows"] == 0 and int(ix.ivf_info()["list_sizes"].sum()) == len(X) + 710
+    finally:
+        _native.diag_set_option("ivf_tail_rows", -1)
+        ix.close(); tailix.close()
+
+
 def test_coarse_stage_without_room_for_its_shadow_leaves_the_exact_probe_in_charge(rt):
     """The centred int8 shadow is a quarter of the corpus again; when it cannot be allocated the batch is probed exactly (same
     results), the stage stays off for this index, and a re-train brings it back."""
@@ -517,6 +571,7 @@ def test_coarse_stage_survives_upserts_and_near_duplicates(rt, metric):
         # more near-duplicates than the refine step takes on: those queries are probed exactly
         dup2 = (X[123][None, :] + 1e-4 * rng.standard_normal((3800, 128))).astype(np.float32)
         ix.add(dup2)
+        ix.ivf_info()  # fold the appended rows into the lists (left alone they would be searched as a tail, outside the coarse stage)
         ix.set_search_mode("ivf_listmajor")
         d7, r7 = ix.search(Q, k=10, nprobe=8)
         ix.set_search_mode("ivf_coarse")
