@@ -75,24 +75,40 @@ def sweep(seed: int, cases: int) -> int:
         # the planner answered exhaustively (small corpora, single queries with a large top_k: exact results, not the probe's)
         modes = ["auto", "ivf_listmajor", "ivf_coarse", "ivf", "auto"] if kind == "IVF_FLAT" else ["auto", "batched", "auto"]
         line = []
-        for mode in modes:
-            try:
-                r, d, st = run(rt, dev, ix, q, k, nprobe, mode)
-            except _native.ScError as e:
-                line.append(f"{mode}: refused ({e.args[0] if e.args else e})")
-                continue
-            ref_mode = "exact" if st["path"] in ("exact", "batched") else "ivf"
-            ref_rows, ref_d, rst = run(rt, dev, ix, q, k, nprobe, ref_mode)
-            same = np.array_equal(r, ref_rows) and np.array_equal(d.view(np.uint32), ref_d.view(np.uint32))
-            if bool(st.get("tail_rows")) != bool(rst.get("tail_rows")):
-                line.append(f"{mode}->{st['path']}: tail state differs from the reference's (not compared)")
-                continue
-            line.append(f"{mode}->{st['path']}{'/wide' if st.get('wide') else ''}{'/tail' if st.get('tail_rows') else ''} vs {rst['path']}: {'same' if same else 'DIFFERENT'}")
-            if not same:
-                bad += 1
-                diffq = np.nonzero((r != ref_rows).any(axis=1) | (d.view(np.uint32) != ref_d.view(np.uint32)).any(axis=1))[0]
-                j = int(diffq[0])
-                print(f"  first differing query {j} of {len(diffq)}: stats {st}\n   ref rows {ref_rows[j][:12]} d {ref_d[j][:6]}\n   got rows {r[j][:12]} d {d[j][:6]}", flush=True)
+        for rnd in range(2):
+            if rnd == 1:
+                # second round on the SAME index after it changed under its shadows (int8 / bf16 / centred copies, norms, lists):
+                # rows overwritten with the queries themselves (each must now be its query's nearest row), or rows appended
+                what = str(rng.choice(["overwrite", "append", "both"]))
+                qh = q.cpu().numpy()
+                if what in ("overwrite", "both"):
+                    m = min(Q, 50)
+                    tgt = rng.choice(len(ix), size=m, replace=False).astype(np.int64)
+                    ix.overwrite(qh[:m], tgt)
+                if what in ("append", "both"):
+                    ix.add(qh[: min(Q, 30)] * np.float32(0.5))
+                line.append(f"[{what}]")
+            for mode in modes:
+                try:
+                    r, d, st = run(rt, dev, ix, q, k, nprobe, mode)
+                except _native.ScError as e:
+                    line.append(f"{mode}: refused ({e.args[0] if e.args else e})")
+                    continue
+                ref_mode = "exact" if st["path"] in ("exact", "batched") else "ivf"
+                ref_rows, ref_d, rst = run(rt, dev, ix, q, k, nprobe, ref_mode)
+                same = np.array_equal(r, ref_rows) and np.array_equal(d.view(np.uint32), ref_d.view(np.uint32))
+                if bool(st.get("tail_rows")) != bool(rst.get("tail_rows")):
+                    line.append(f"{mode}->{st['path']}: tail state differs from the reference's (not compared)")
+                    continue
+                line.append(f"{mode}->{st['path']}{'/wide' if st.get('wide') else ''}{'/tail' if st.get('tail_rows') else ''} vs {rst['path']}: {'same' if same else 'DIFFERENT'}")
+                if rnd == 1 and metric == "L2" and shape != "tight" and what != "append" and not all(np.array_equal(ix.get_rows(int(r[j, 0]), 1)[0], qh[j]) for j in range(m)):
+                    same = False  # (an overwritten row IS its query: distance 0 on every path, whatever the reference says)
+                    line.append("an overwritten row was not found")
+                if not same:
+                    bad += 1
+                    diffq = np.nonzero((r != ref_rows).any(axis=1) | (d.view(np.uint32) != ref_d.view(np.uint32)).any(axis=1))[0]
+                    j = int(diffq[0]) if len(diffq) else 0
+                    print(f"  first differing query {j} of {len(diffq)}: stats {st}\n   ref rows {ref_rows[j][:12]} d {ref_d[j][:6]}\n   got rows {r[j][:12]} d {d[j][:6]}", flush=True)
         print(f"case {case}: rows {rows} dim {dim} {metric} {kind} nlist {nlist} nprobe {nprobe} Q {Q} k {k} {shape} {' '.join(events)} | " + " | ".join(line), flush=True)
         ix.close()
         del q
