@@ -30,8 +30,8 @@ def sweep(seed: int, cases: int) -> int:
     t_all = time.time()
     for case in range(cases):
         rows = int(rng.choice([3000, 70_000, 130_000, 300_000, 1_100_000, 2_500_000]))
-        dim = int(rng.choice([64, 128, 384, 768, 1024]))
-        if rows * dim > 600_000_000:
+        dim = int(rng.choice([64, 128, 384, 768, 1024, 7, 100, 200, 1000, 1536, 3072]))
+        if rows * dim > 1_500_000_000:
             dim = 384
         metric = str(rng.choice(["L2", "IP", "COSINE"]))
         kind = str(rng.choice(["FLAT", "IVF_FLAT"]))
@@ -49,7 +49,10 @@ def sweep(seed: int, cases: int) -> int:
         else:
             ix.fill_synthetic_clustered(rows, seed=case, nclusters=int(rng.choice([8, 200, 3000])), spread=0.02 if shape == "tight" else 0.3)
         q = torch.empty((Q, dim), dtype=torch.float32, device=dev)
-        rt.synth_fill_dev(q.data_ptr(), Q, dim, dim, seed=1000 + case)
+        if dim % 4 == 0:
+            rt.synth_fill_dev(q.data_ptr(), Q, dim, dim, seed=1000 + case)
+        else:
+            q.copy_(torch.from_numpy(rng.uniform(-1, 1, size=(Q, dim)).astype(np.float32)))
         # some queries are corpus rows (distance 0 / a tie with a planted duplicate), one query is repeated
         nself = min(Q, 1 + Q // 8)
         pick = rng.integers(0, rows, size=nself)
