@@ -41,11 +41,13 @@ template <bool UNIT>
 __global__ __launch_bounds__(256) void ivf_center_shadow_kernel(const float* __restrict__ X, int64_t rows, int ld, int ld8, const float* __restrict__ C, int ldc,
                                                                  const int64_t* __restrict__ list_off, int nlist, int8_t* __restrict__ Xc8,
                                                                  f32x4* __restrict__ xrow, unsigned* __restrict__ list_stats,
-                                                                 const float* __restrict__ xnorm, const float* __restrict__ cnorm) {
+                                                                 const float* __restrict__ xnorm, const float* __restrict__ cnorm,
+                                                                 const int64_t* __restrict__ only) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t r = wave0; r < rows; r += nwaves) {
+    for (int64_t i = wave0; i < rows; i += nwaves) {
+        const int64_t r = only ? only[i] : i;  // (only: the stored positions of rows overwritten in place, `rows` of them)
         const int l = list_of_pos(list_off, nlist, r);
         const float* x = X + r * (int64_t)ld;
         const float* c = C + (int64_t)l * ldc;
@@ -233,16 +235,16 @@ __global__ __launch_bounds__(256) void ivf_slot_thr_kernel(const int32_t* __rest
 }
 
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm, const float* cnorm) {
+                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm, const float* cnorm, const int64_t* only) {
     if (rows <= 0) return;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (xnorm && cnorm)
         hipLaunchKernelGGL(ivf_center_shadow_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow,
-                           list_stats, xnorm, cnorm);
+                           list_stats, xnorm, cnorm, only);
     else
         hipLaunchKernelGGL(ivf_center_shadow_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, ld, ld8, C, ldc, list_off, nlist, (int8_t*)Xc8, (f32x4*)xrow,
-                           list_stats, (const float*)nullptr, (const float*)nullptr);
+                           list_stats, (const float*)nullptr, (const float*)nullptr, only);
 }
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
                               const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,

@@ -345,6 +345,7 @@ extern "C" sc_status sc_index_overwrite(sc_index* ix, const float* vecs, const i
 // rows[i] <- vecs[i], appends allowed (see include/semcode_hip.h sc_index_put_rows).  vecs: host or device [n, dim].
 sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on_device, const int64_t* rows, int64_t n, const char* who) {
     int64_t next = ix->n, min_old = INT64_MAX;
+    const int64_t old_n = ix->n;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = rows[i];
         if (r == next) ++next;
@@ -409,9 +410,23 @@ sc_status sc_index_put_rows_locked(sc_index* ix, const float* vecs, bool vecs_on
     }
     ix->n = next;
     if (!ix->perm) ix->trained = false;
-    if (min_old < ix->shadow_rows) ix->shadow_rows = 0;  // replaced rows invalidate the shadows; appended rows get theirs lazily
-    if (min_old < ix->shadow8_rows) ix->shadow8_rows = 0;
-    if (min_old != INT64_MAX) ix->shadowc_rows = 0;  // (the centred shadow of the IVF coarse stage is rebuilt with the lists)
+    // replaced rows: their shadow rows are stale.  Remembered by stored position and re-built alone before the next search that reads
+    // the shadow (ensure_shadow / ensure_shadow8 / ivfc_ensure_shadow); appended rows get theirs lazily as before.  `rows` holds
+    // stored positions here, old_n the row count before this call.
+    if (min_old != INT64_MAX) {
+        auto note = [&](std::vector<int64_t>& dirty, int64_t& covered) {
+            if (covered == 0) return;
+            for (int64_t i = 0; i < n; ++i)
+                if (row_ids[i] < old_n && rows[i] < covered) dirty.push_back(rows[i]);
+            if ((int64_t)dirty.size() > sc_index::SC_SHADOW_DIRTY_MAX) {  // too many single rows: the whole shadow in one pass is cheaper
+                dirty.clear();
+                covered = 0;
+            }
+        };
+        note(ix->dirty_b16, ix->shadow_rows);
+        note(ix->dirty_i8, ix->shadow8_rows);
+        note(ix->dirty_c8, ix->shadowc_rows);
+    }
     return SC_OK;
 }
 
@@ -596,6 +611,21 @@ static sc_status search_exact_range_locked(sc_index* ix, const float* q_dev, int
 
 // ---- batched path (scan_batched.hip): bf16 shadow + coarse GEMM phases + exact re-rank + certified fallback
 
+// the rows of a dirty list as runs (first, count) of stored positions, ascending; neighbours up to 32 rows apart share a run (re-building
+// a clean row in between changes nothing).  Empties the list.
+static std::vector<std::pair<int64_t, int64_t>> dirty_runs(std::vector<int64_t>& dirty, int64_t covered) {
+    std::sort(dirty.begin(), dirty.end());
+    dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    for (const int64_t r : dirty) {
+        if (r >= covered) break;
+        if (!runs.empty() && r < runs.back().first + runs.back().second + 32) runs.back().second = r + 1 - runs.back().first;
+        else runs.emplace_back(r, 1);
+    }
+    dirty.clear();
+    return runs;
+}
+
 static sc_status ensure_shadow(sc_index* ix) {
     hipStream_t s = ix->rt->stream;
     const int64_t rows_pad = (ix->n + 255) / 256 * 256;
@@ -625,6 +655,12 @@ static sc_status ensure_shadow(sc_index* ix) {
             SC_HIP(hipMemsetAsync((char*)ix->Xb + (size_t)ix->n * ix->ld * 2, 0, (size_t)(rows_pad - ix->n) * ix->ld * 2, s));
         sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max, s);
         ix->shadow_rows = ix->n;
+        SC_HIP(hipGetLastError());
+    }
+    if (!ix->dirty_b16.empty()) {  // rows overwritten since: their shadow rows alone (the maxima keep accumulating)
+        for (const auto& run : dirty_runs(ix->dirty_b16, ix->shadow_rows))
+            sc_launch_shadow(ix->X, ix->xnorm, run.first, run.second, ix->ld, ix->Xb, ix->xnorm_max + 1, s);
+        sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max, s);
         SC_HIP(hipGetLastError());
     }
     return SC_OK;
@@ -667,6 +703,12 @@ static sc_status ensure_shadow8(sc_index* ix) {
         }
         sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max8, s);
         ix->shadow8_rows = ix->n;
+        SC_HIP(hipGetLastError());
+    }
+    if (!ix->dirty_i8.empty()) {
+        for (const auto& run : dirty_runs(ix->dirty_i8, ix->shadow8_rows))
+            sc_launch_shadow8(ix->X, ix->xnorm, run.first, run.second, ix->ld, ld8, ix->Xq, ix->xscale, ix->xnorm_max8 + 1, s);
+        sc_launch_norm_max(ix->xnorm, ix->n, ix->xnorm_max8, s);
         SC_HIP(hipGetLastError());
     }
     return SC_OK;

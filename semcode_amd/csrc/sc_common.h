@@ -170,7 +170,7 @@ void sc_launch_scan_rerank(int metric, const float* X, const float* xnorm, int l
 
 // ivf_coarse.hip + scan_batched.hip: the int8 coarse stage of list-major IVF probing (L2)
 void sc_launch_ivf_center_shadow(const float* X, int64_t rows, int ld, int ld8, const float* C, int ldc, const int64_t* list_off, int nlist, void* Xc8,
-                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm = nullptr, const float* cnorm = nullptr);  // norms: COSINE
+                                 float* xrow, unsigned* list_stats, hipStream_t s, const float* xnorm = nullptr, const float* cnorm = nullptr, const int64_t* only = nullptr);  // norms: COSINE
 void sc_launch_ivf_pair_query(const float* Qp, int ld, int ld8, const float* C, int ldc, const int32_t* slot_q, const int32_t* slot_l, int nslots,
                               const unsigned* list_stats, void* Qc8, float* slot_qs, float* slot_qnlb, float* slot_qb, float* slot_qd, float* slot_eps, hipStream_t s,
                               int metric = SC_METRIC_L2, const float* qnorm = nullptr, const float* cnorm = nullptr);

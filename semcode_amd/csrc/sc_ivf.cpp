@@ -839,7 +839,30 @@ bool sc_ivf_coarse_applicable(const sc_index* ix, int Q, int k, int nprobe) {
 static int g_ivfc_nomem = 0;  // sc_diag_set_option("ivf_coarse_nomem", 1): the centred shadow cannot be allocated (tests of the fallback to the exact probe)
 void sc_ivf_set_coarse_nomem(int v) { g_ivfc_nomem = v; }
 static sc_status ivfc_ensure_shadow(sc_index* ix) {
-    if (ix->shadowc_rows == ix->ivf_rows && ix->Xc8) return SC_OK;
+    if (ix->shadowc_rows == ix->ivf_rows && ix->Xc8) {
+        if (ix->dirty_c8.empty()) return SC_OK;
+        // rows of the lists overwritten in place and still in their lists (sc_ivf_refresh_locked found nothing to move, or the layout
+        // would have been rebuilt and this shadow with it): their shadow rows alone; the per-list maxima keep accumulating
+        hipStream_t s = ix->rt->stream;
+        std::vector<int64_t>& d = ix->dirty_c8;
+        std::sort(d.begin(), d.end());
+        d.erase(std::unique(d.begin(), d.end()), d.end());
+        while (!d.empty() && d.back() >= ix->shadowc_rows) d.pop_back();
+        if (!d.empty()) {
+            sc_status st = sc_grow(ix, (void**)&ix->stage, &ix->stage_cap, d.size() * 8);
+            if (st) return st;
+            SC_HIP(hipMemcpyAsync(ix->stage, d.data(), d.size() * 8, hipMemcpyHostToDevice, s));
+            const bool unit = ix->metric == SC_METRIC_COSINE;
+            sc_launch_ivf_center_shadow(ix->X, (int64_t)d.size(), ix->ld, ivfc_ld8(ix), ix->quant->X, ix->quant->ld, ix->list_off, ix->nlist_trained, ix->Xc8, ix->xcs,
+                                        ix->list_stats, s, unit ? ix->xnorm : nullptr, unit ? ix->quant->xnorm : nullptr, (const int64_t*)ix->stage);
+            sc_launch_norm_max(ix->xnorm, ix->shadowc_rows, ix->list_stats + (size_t)ix->nlist * 2, s);
+            SC_HIP(hipGetLastError());
+            SC_HIP(hipStreamSynchronize(s));  // (the position list is a host temporary behind an asynchronous copy)
+        }
+        d.clear();
+        return SC_OK;
+    }
+    ix->dirty_c8.clear();  // a full build covers them
     if (g_ivfc_nomem) return sc_fail(SC_ERR_NOMEM, "ivf coarse stage: out of device memory (forced by sc_diag_set_option)");
     hipStream_t s = ix->rt->stream;
     const int ld8 = ivfc_ld8(ix), nlist = ix->nlist_trained;

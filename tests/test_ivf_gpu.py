@@ -582,3 +582,49 @@ def test_coarse_stage_survives_upserts_and_near_duplicates(rt, metric):
     finally:
         _native.diag_set_option("ivf_refine_cap", -1)
         ix.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+def test_rows_overwritten_in_their_lists_refresh_their_shadow_rows_only(rt, metric):
+    """A re-index of unchanged or slightly changed chunks overwrites rows that stay in their lists: no re-layout, and the shadows the
+    coarse stages read (centred int8 of the IVF stage; int8 / bf16 of the exhaustive batched path) re-build the rows that changed, not
+    themselves.  Every path must see the NEW vectors: same bits as the per-query probe / the exact scan, and (L2) each query that
+    equals an overwritten row finds it first."""
+    X, centers = clustered(150_000, 64, 40, seed=131)
+    rng = np.random.default_rng(132)
+    ix = _native.Index(rt, 64, metric=metric, kind="IVF_FLAT", nlist=32)
+    try:
+        ix.add(X)
+        ix.train(niter=4)
+        sizes = ix.ivf_info()["list_sizes"].copy()
+        Q0 = (centers[rng.integers(0, 40, size=90)] + 0.3 * rng.standard_normal((90, 64))).astype(np.float32)
+        for mode in ("ivf_coarse", "batched"):  # build the shadows on the old rows
+            ix.set_search_mode(mode)
+            ix.search(Q0, k=10, nprobe=5)
+        for rnd in range(3):
+            tgt = np.sort(rng.choice(len(X), size=60, replace=False)).astype(np.int64)
+            new = (X[tgt] * np.float32(1.0 + 2e-3 * (rnd + 1)) + np.float32(1e-3) * rng.standard_normal((60, 64))).astype(np.float32)  # stays in its list
+            ix.overwrite(new, tgt)
+            X[tgt] = new
+            Q = Q0.copy()
+            Q[:60] = new
+            ix.set_search_mode("ivf")
+            dr, rr = ix.search(Q, k=10, nprobe=5)
+            for mode in ("ivf_coarse", "ivf_listmajor", "auto"):
+                ix.set_search_mode(mode)
+                d, r = ix.search(Q, k=10, nprobe=5)
+                assert ix.last_search_stats()["path"].startswith("ivf"), mode
+                assert np.array_equal(r, rr) and np.array_equal(bits(d), bits(dr)), (mode, rnd)
+            ix.set_search_mode("exact")
+            de, re_ = ix.search(Q, k=10)
+            ix.set_search_mode("batched")
+            d, r = ix.search(Q, k=10)
+            assert ix.last_search_stats()["path"] == "batched"
+            assert np.array_equal(r, re_) and np.array_equal(bits(d), bits(de)), rnd
+            want_d, want_r = orc.search(X, Q[:8], 10, metric)
+            assert np.array_equal(re_[:8], want_r) and np.array_equal(bits(de[:8]), bits(want_d))
+            if metric == "L2":
+                assert (rr[:60, 0] == tgt).all() and (re_[:60, 0] == tgt).all()
+        assert np.array_equal(ix.ivf_info()["list_sizes"], sizes)  # nothing moved
+    finally:
+        ix.close()
