@@ -206,8 +206,9 @@ sc_status sc_ivf_refresh_locked(sc_index* ix) {
     std::sort(rows.begin(), rows.end());
     rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
     for (int64_t r = ix->ivf_rows; r < ix->n; ++r) rows.push_back(r);
-    std::vector<int32_t> assign(ix->assign_h);
-    assign.resize((size_t)ix->n, -1);
+    // (the new lists of the rows are collected first: the copy of the whole assignment -- 40 MB at 10M rows, most of what a refresh that
+    // moves nothing used to cost -- is made only when something does move)
+    std::vector<int32_t> new_list(rows.size());
     bool changed = ix->n > ix->ivf_rows;
     const int64_t CH = 65536;
     Dev d_pos, d_tight;
@@ -226,14 +227,17 @@ sc_status sc_ivf_refresh_locked(sc_index* ix) {
         if (st) return st;
         for (int64_t i = 0; i < m; ++i) {
             const int64_t r = rows[(size_t)(c0 + i)];
-            if (assign[(size_t)r] != out[(size_t)i]) changed = true;
-            assign[(size_t)r] = out[(size_t)i];
+            if (r >= (int64_t)ix->assign_h.size() || ix->assign_h[(size_t)r] != out[(size_t)i]) changed = true;
+            new_list[(size_t)(c0 + i)] = out[(size_t)i];
         }
     }
     if (!changed) {  // overwritten rows all stayed in their lists: nothing moves
         ix->dirty_rows.clear();
         return SC_OK;
     }
+    std::vector<int32_t> assign(ix->assign_h);
+    assign.resize((size_t)ix->n, -1);
+    for (size_t i = 0; i < rows.size(); ++i) assign[(size_t)rows[i]] = new_list[i];
     return ivf_install_lists_locked(ix, ix->nlist_trained, std::move(assign));
 }
 
