@@ -1106,7 +1106,15 @@ static sc_status search_dev_locked(sc_index* ix, const float* q_dev, int32_t Q, 
     // exhaustive search, the lists are refreshed as before.  A tail row is always seen -- the probed lists plus the whole tail --
     // so recall can only be higher than after the refresh.
     {
-        const int64_t tail = (ix->kind == SC_INDEX_IVF_FLAT && ix->trained && ix->perm) ? ix->n - ix->ivf_rows : 0;
+        int64_t tail = (ix->kind == SC_INDEX_IVF_FLAT && ix->trained && ix->perm) ? ix->n - ix->ivf_rows : 0;
+        if (tail > 0 && tail <= g_ivf_tail_rows && !ix->dirty_rows.empty() && ix->search_mode != 1 && ix->search_mode != 2) {
+            // listed rows were overwritten as well (a re-index: known chunks again, new ones appended): settle those first -- rows that
+            // stayed in their lists (unchanged or lightly edited chunks) leave the layout alone and the tail a tail
+            const sc_status rst = sc_ivf_refresh_locked(ix, true);
+            if (rst && rst != SC_ERR_NOMEM) return rst;
+            if (rst) (void)hipGetLastError();
+            tail = ix->n - ix->ivf_rows;
+        }
         if (tail > 0 && tail <= g_ivf_tail_rows && ix->dirty_rows.empty() && ix->search_mode != 1 && ix->search_mode != 2 && nprobe >= 1 && nprobe < ix->nlist_trained &&
             (sc_ivf_coarse_applicable(ix, Q, k, nprobe) || sc_ivf_applicable(ix, Q, nprobe) ||
              sc_ivf_listmajor_applicable(ix, Q, k, nprobe, batched_applicable(ix, Q, k)))) {

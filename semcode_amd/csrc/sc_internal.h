@@ -136,7 +136,8 @@ sc_status sc_ivf_search_coarse_locked(sc_index* ix, const float* q_dev, int32_t 
 sc_status sc_ivf_untrain_locked(sc_index* ix);  // restore insertion order, drop lists
 void sc_ivf_drop_lists_locked(sc_index* ix);    // drop lists without restoring the order (the rows are about to be discarded)
 sc_status sc_ivf_cover_tail_locked(sc_index* ix);  // extend perm over rows appended since the build (identity): exhaustive search only
-sc_status sc_ivf_refresh_locked(sc_index* ix);  // fold rows upserted since the lists were built into them (no k-means)
+sc_status sc_ivf_refresh_locked(sc_index* ix, bool keep_tail = false);  // fold rows upserted since the lists were built into them (no k-means);
+                                                                        // keep_tail: only settle the overwritten rows -- if none left its list, appended rows stay a tail
 // stored position of row `r` (trained layout installed: ix->perm != nullptr)
 static inline int64_t sc_ivf_pos(const sc_index* ix, int64_t r) { return r < ix->ivf_rows ? (int64_t)ix->inv_h[(size_t)r] : r; }
 // upsert body shared by sc_index_put_rows{,_dev} and sc_encoder_embed_ids_into; caller holds ix->mu and has set the device

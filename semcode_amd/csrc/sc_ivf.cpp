@@ -198,18 +198,20 @@ sc_status sc_ivf_cover_tail_locked(sc_index* ix) {
     return SC_OK;
 }
 
-sc_status sc_ivf_refresh_locked(sc_index* ix) {
+sc_status sc_ivf_refresh_locked(sc_index* ix, bool keep_tail) {
     if (!ix->perm || !ix->quant || (ix->ivf_rows == ix->n && ix->dirty_rows.empty())) return SC_OK;
+    if (keep_tail && ix->dirty_rows.empty()) return SC_OK;
     if (g_ivf_refresh_nomem) return sc_fail(SC_ERR_NOMEM, "ivf refresh: out of device memory (forced by sc_diag_set_option)");
     hipStream_t s = ix->rt->stream;
     std::vector<int64_t> rows(ix->dirty_rows);
     std::sort(rows.begin(), rows.end());
     rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-    for (int64_t r = ix->ivf_rows; r < ix->n; ++r) rows.push_back(r);
+    if (!keep_tail)
+        for (int64_t r = ix->ivf_rows; r < ix->n; ++r) rows.push_back(r);
     // (the new lists of the rows are collected first: the copy of the whole assignment -- 40 MB at 10M rows, most of what a refresh that
     // moves nothing used to cost -- is made only when something does move)
     std::vector<int32_t> new_list(rows.size());
-    bool changed = ix->n > ix->ivf_rows;
+    bool changed = !keep_tail && ix->n > ix->ivf_rows;
     const int64_t CH = 65536;
     Dev d_pos, d_tight;
     const int64_t chmax = std::min<int64_t>(CH, (int64_t)rows.size());
@@ -235,6 +237,7 @@ sc_status sc_ivf_refresh_locked(sc_index* ix) {
         ix->dirty_rows.clear();
         return SC_OK;
     }
+    if (keep_tail) return sc_ivf_refresh_locked(ix, false);  // a row left its list: the layout is rebuilt, the tail joins it
     std::vector<int32_t> assign(ix->assign_h);
     assign.resize((size_t)ix->n, -1);
     for (size_t i = 0; i < rows.size(); ++i) assign[(size_t)rows[i]] = new_list[i];

@@ -626,5 +626,24 @@ def test_rows_overwritten_in_their_lists_refresh_their_shadow_rows_only(rt, metr
             if metric == "L2":
                 assert (rr[:60, 0] == tgt).all() and (re_[:60, 0] == tgt).all()
         assert np.array_equal(ix.ivf_info()["list_sizes"], sizes)  # nothing moved
+        # a re-index: new chunks appended AND known ones overwritten in their lists -- the appended rows stay a tail (no re-layout)
+        T = (centers[rng.integers(0, 40, size=300)] + 0.3 * rng.standard_normal((300, 64))).astype(np.float32)
+        ix.add(T)
+        tgt = np.sort(rng.choice(150_000, size=60, replace=False)).astype(np.int64)
+        new = (X[tgt] * np.float32(1.004)).astype(np.float32)
+        ix.overwrite(new, tgt)
+        X[tgt] = new
+        Q = Q0.copy()
+        Q[:60] = new
+        Q[60:80] = T[:20]
+        got = {}
+        for mode in ("ivf_coarse", "ivf", "ivf_listmajor"):
+            ix.set_search_mode(mode)
+            got[mode] = ix.search(Q, k=10, nprobe=5)
+            assert ix.last_search_stats()["tail_rows"] == 300, (mode, ix.last_search_stats())
+        for mode in ("ivf_coarse", "ivf_listmajor"):
+            assert np.array_equal(got[mode][1], got["ivf"][1]) and np.array_equal(bits(got[mode][0]), bits(got["ivf"][0])), mode
+        if metric == "L2":
+            assert (got["ivf"][1][:60, 0] == tgt).all() and (got["ivf"][1][60:80, 0] == 150_000 + np.arange(20)).all()
     finally:
         ix.close()
